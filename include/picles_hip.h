@@ -1,0 +1,188 @@
+/*
+ * picles_hip.h — C ABI of the MI355X-native PiCLES 2D particle-in-cell time step.
+ *
+ * This header IS the drop-in boundary.  The reference (mochell/PiCLES, pure Julia)
+ * has no FFI layer of its own; the functions a replacement must provide are the
+ * Julia methods of Operators.TimeSteppers / Simulations listed next to each entry
+ * point below (file:line are into the reference tree).  A Julia maintainer binds
+ * them with `ccall`; the in-repo Python host layer
+ * (picles_amd/) binds the very same symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns int32: 0 = OK, <0 = error (text via picles_last_error)
+ *   - all arrays handed across the ABI are caller-owned HOST memory unless the
+ *     name says `_dev`; the library never frees caller memory and never calls back
+ *   - fields are column-major [i + Nx*(j + Ny*k)] exactly like the reference's
+ *     State[Nx,Ny,3] (k = e, m_x, m_y)   (WaveGrowthModels2D.jl:136-143)
+ *   - a context belongs to ONE GPU (one process per GPU) and owns the rows
+ *     [j_begin, j_end) of the global grid (y-slab); single-GPU use: 0, Ny
+ *   - a context is not re-entrant (the reference calls time_step! from one task)
+ *   - there is NO CPU fallback: creating a context without a HIP device fails
+ */
+#ifndef PICLES_HIP_H
+#define PICLES_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PICLES_ABI_VERSION 1
+
+/* ---- grid: TwoDCartesianGridStatistics + mesh mask (Grids/CartesianGrid.jl:26-101,
+ *      Grids/mask_utils.jl:38-55) ------------------------------------------------ */
+typedef struct picles_grid {
+    int32_t Nx, Ny;          /* global node counts                                   */
+    double  dx, dy;          /* node spacing [m]; ProjetionKernel M = diag(1/dx,1/dy) */
+    int32_t periodic_x;      /* 1: Nx isa N_Periodic, 0: N_NonPeriodic (scatter wrap/drop) */
+    int32_t periodic_y;
+    const int8_t *mask;      /* Nx*Ny total mask {0 land,1 ocean,2 land bnd,3 grid bnd};
+                                NULL => all ocean + make_boundaries() ring on non-periodic axes */
+    int32_t j_begin, j_end;  /* rows owned by this context (slab); 0, Ny for one device */
+} picles_grid;
+
+/* ---- physics: ODEParameters NamedTuple + particle_equations kwargs
+ *      (particle_waves_v5.jl:107-128,154-162,184-196,382-395) -------------------- */
+typedef struct picles_phys {
+    double r_g, C_alpha, C_phi, C_e, g;   /* params NamedTuple (g is carried but, as in the
+                                             reference :281-287,504, NOT used by the RHS)   */
+    double gamma, q;                      /* particle_equations(u,v; γ, q)                  */
+    double c_beta, c_D, c_e, c_alpha;     /* IDConstants fields entering e_T_func :271      */
+    int32_t propagation, input, dissipation, peak_shift, direction;  /* RHS switches :383-387 */
+} picles_phys;
+
+/* ---- ODESettings (particle_waves_v5.jl:34-75) ---------------------------------- */
+typedef struct picles_ode {
+    double  abstol, reltol;
+    double  dt0;             /* ODESettings.dt : initial dt of a freshly built integrator   */
+    double  dtmin;
+    int32_t force_dtmin;
+    int32_t solver;          /* 0 = DP5 (Dormand-Prince 5(4), bench06:93)                   */
+    int64_t maxiters;        /* per model step                        */
+    double  log_energy_minimum, log_energy_maximum, wind_min_squared;
+    double  timestep;        /* ODESettings.timestep: seed time-scale of init_particles!    */
+} picles_ode;
+
+/* ---- model flags (WaveGrowthModels2D.jl:194-345) ------------------------------- */
+typedef struct picles_model {
+    int32_t periodic_boundary;   /* model flag: selects ocean_points / boundary flag        */
+    int32_t init_type;           /* 0 "wind_sea" (ODEdefaults = nothing); 1 fixed ParticleDefaults */
+    double  default_particle[3]; /* lne, c̄_x, c̄_y when init_type == 1                      */
+    double  minimal_state[2];    /* [E_min, m²_min]  (FetchRelations.MinimalState)          */
+} picles_model;
+
+/* flags of picles_time_step */
+#define PICLES_STEP_ZERO_FIRST   1  /* run!: State .= 0 before time_step!  (run.jl:75-82)    */
+#define PICLES_STEP_MOVIE        2  /* movie_time_step!: snapshot State->MovieState between
+                                       advance and remesh, zero State after  (TimeSteppers.jl:212-247) */
+#define PICLES_STEP_ATOMIC       4  /* scatter with the LDS-tiled fp64-atomic push instead of the
+                                       deterministic (bitwise reproducible) pull                 */
+
+/* per-particle status bits (returned by picles_get_particles) */
+#define PICLES_ST_STEPPED        1  /* particle is in ocean_points                              */
+#define PICLES_ST_MAXITERS       2  /* internal RK loop hit maxiters in the last advance        */
+#define PICLES_ST_RESEED_NAN     4  /* NaN guard re-seeded (mapping_2D.jl:196-211)              */
+#define PICLES_ST_RESEED_INF     8  /* Inf guard re-seeded (:213-222)                           */
+#define PICLES_ST_CLAMPED       16  /* lne clamped to log_energy_maximum (:224-235)             */
+#define PICLES_ST_SWITCHED_ON   32  /* off -> on by wind test in advance (:172-185)             */
+#define PICLES_ST_DTMIN         64  /* stopped: dt <= dtmin without force_dtmin                 */
+#define PICLES_ST_NONFINITE    128  /* a non-finite error estimate was rejected                 */
+
+typedef struct picles_counters {
+    uint64_t rhs_evals;       /* RHS evaluations                      */
+    uint64_t steps_accepted;  /* accepted internal RK steps           */
+    uint64_t steps_rejected;
+    uint64_t reseeds;         /* NaN/Inf guards + off->on + remesh B/C */
+    uint64_t clamps;
+    uint64_t maxiters_hits;
+    uint64_t particles_advanced;  /* particles that ran the ODE       */
+    uint64_t halo_overflow;   /* particles that travelled beyond the scatter reach used */
+    int32_t  max_reach;       /* max |cell offset| any scatter corner had in the last advance */
+    int32_t  _pad;
+} picles_counters;
+
+typedef struct picles_timing {     /* accumulated device time, ms (HIP events on the compute stream) */
+    double advance_ms, scatter_ms, remesh_ms, other_ms;
+    uint64_t advance_launches, scatter_launches, remesh_launches;
+} picles_timing;
+
+typedef struct picles_ctx picles_ctx;
+
+/* WaveGrowth2D(...) constructor: allocates State, particles (WaveGrowthModels2D.jl:194-345).
+ * device_id: HIP device ordinal.  halo_rows: ghost rows kept on each side of the slab
+ * (>= the scatter reach in y; ignored for a single slab covering [0,Ny) ). */
+int32_t picles_create(const picles_grid *g, const picles_phys *p, const picles_ode *o,
+                      const picles_model *m, int32_t device_id, int32_t halo_rows,
+                      picles_ctx **out);
+int32_t picles_destroy(picles_ctx *ctx);
+const char *picles_last_error(const picles_ctx *ctx);   /* ctx may be NULL: last create() error */
+int32_t picles_abi_version(void);
+
+/* winds: node-sampled u,v (col-major, the context's own rows only: Nx*(j_end-j_begin))
+ * at two time levels; the RHS lerps in t.  u1==NULL => time-constant.
+ * Replaces the Julia closures winds.u(x,y,t) (particle_waves_v5.jl:494-495). */
+int32_t picles_set_winds(picles_ctx *ctx, const double *u0, const double *v0, double t0,
+                         const double *u1, const double *v1, double t1);
+
+/* init_particles!(model) + SeedParticle (run.jl:199-247, core_2D.jl:434-488); clock := t0 */
+int32_t picles_seed(picles_ctx *ctx, double t0);
+
+/* time_step!(model, Δt) / movie_time_step! (TimeSteppers.jl:109-166,212-247) */
+int32_t picles_time_step(picles_ctx *ctx, double dt, int32_t flags);
+/* time_step!_advance / time_step!_remesh (TimeSteppers.jl:168-193); remesh does NOT tick */
+int32_t picles_advance(picles_ctx *ctx, double dt, int32_t flags);
+int32_t picles_remesh(picles_ctx *ctx, double dt);
+int32_t picles_tick(picles_ctx *ctx, double dt);          /* tick!(clock, Δt) :163 */
+int32_t picles_zero_state(picles_ctx *ctx);               /* State .= 0  (run.jl:75-79) */
+double  picles_clock(const picles_ctx *ctx);
+
+/* State / MovieState access (own rows; 3 planes of Nx*(j_end-j_begin)) */
+int32_t picles_get_state(picles_ctx *ctx, double *state);
+int32_t picles_set_state(picles_ctx *ctx, const double *state);
+int32_t picles_get_movie_state(picles_ctx *ctx, double *state);
+
+/* particles (own rows; z is 5 planes: lne, c̄x, c̄y, x, y). Any pointer may be NULL. */
+int32_t picles_get_particles(picles_ctx *ctx, double *z, uint8_t *on, uint8_t *boundary,
+                             int32_t *status);
+int32_t picles_set_particles(picles_ctx *ctx, const double *z, const uint8_t *on);
+
+int32_t picles_get_counters(picles_ctx *ctx, picles_counters *c);   /* syncs */
+int32_t picles_reset_counters(picles_ctx *ctx);
+int32_t picles_enable_timing(picles_ctx *ctx, int32_t on);
+int32_t picles_get_timing(picles_ctx *ctx, picles_timing *t);       /* syncs */
+int32_t picles_sync(picles_ctx *ctx);
+
+/* ---- split phases for the slab-partitioned (multi-GPU) step -------------------
+ * One model step on rank r:
+ *   picles_advance_rows(EDGE)  -> edge rows' scatter records are final
+ *   [host: exchange picles_halo_send_dev -> neighbour's picles_halo_recv_dev (RCCL)]
+ *   picles_advance_rows(INTERIOR)   (overlaps the exchange on another stream)
+ *   picles_scatter_remesh()    -> pull-scatter own rows from own + ghost records, remesh
+ * Streams are caller-provided HIP streams (void* = hipStream_t; NULL = context stream). */
+#define PICLES_ROWS_ALL      0
+#define PICLES_ROWS_EDGE     1
+#define PICLES_ROWS_INTERIOR 2
+int32_t picles_begin_step(picles_ctx *ctx, double dt, int32_t flags);
+int32_t picles_advance_rows(picles_ctx *ctx, int32_t which, void *stream);
+int32_t picles_scatter_remesh(picles_ctx *ctx, void *stream);  /* + tick */
+/* device pointers + byte count of the contiguous halo blocks (halo_rows record rows each):
+ * side 0 = low-j neighbour, 1 = high-j neighbour */
+int32_t picles_halo_send_dev(picles_ctx *ctx, int32_t side, void **ptr, size_t *bytes);
+int32_t picles_halo_recv_dev(picles_ctx *ctx, int32_t side, void **ptr, size_t *bytes);
+int32_t picles_halo_rows(const picles_ctx *ctx);
+int32_t picles_set_halo_rows(picles_ctx *ctx, int32_t halo_rows);  /* re-allocates records */
+
+/* ---- generic particle->mesh scatter of an arbitrary particle list --------------
+ * (ParticleInCell.push_to_grid! over a list, ParticleInCell.jl:341-376,530-538):
+ * counting-sort into a cell list, LDS-staged grid tiles, wavefront-reduced fp64 atomics.
+ * ij: 2*n int32 (0-based birth node), xy: 2*n positions in cell units relative to ij,
+ * charge: 3*n (e,mx,my), all SoA planes.  Adds into State. */
+int32_t picles_scatter_particles(picles_ctx *ctx, int64_t n, const int32_t *ij,
+                                 const double *xy, const double *charge);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICLES_HIP_H */

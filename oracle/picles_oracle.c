@@ -1,0 +1,932 @@
+/*
+ * picles_oracle.c — CPU restatement of the PiCLES 2D particle-in-cell time step.
+ *
+ * *** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (picles_amd/, libpicles_hip.so) never imports, links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" against the true Julia reference for the ODE stepping.
+ * The reference holds no assertions and exactly one numeric literal on this path
+ * (benchmark/bench02_PW5_allocation.jl:49-50, the seed state for winds (0.1,-0.1), T=300 s),
+ * which this file reproduces (tests/test_oracle_golden.py).  Julia is not installed here and
+ * the time integration is an unvendored, unpinned third-party dependency
+ * (OrdinaryDiffEq.jl DP5 / AutoTsit5, reference Project.toml:6-46); its published
+ * algorithm (Dormand-Prince 5(4) + PI controller + Hairer initial step) is restated below and
+ * cross-checked against SciPy's RK45/DOP853 in tests/.
+ *
+ * Every function cites the reference file:line it follows (paths into mochell/PiCLES).
+ *
+ * Two arithmetic "orders" are provided (runtime switch):
+ *   order 0  LITERAL  : the reference's evaluation order, no fused multiply-adds.
+ *   order 1  KERNEL   : the same formulas re-associated exactly as the HIP kernels evaluate
+ *                       them (shared reciprocals, explicit fma, cross-product form of
+ *                       sin 2(a-b)); independent restatement of DESIGN.md section "Kernel order".
+ * Two math back-ends (compile-time): glibc libm (default) or -DPO_PMATH: the deterministic
+ * primitives of picles_amd/csrc/pmath.h, which make GPU-vs-oracle a bitwise comparison.
+ *
+ * Build: see oracle/Makefile  (-O2 -ffp-contract=off [-fopenmp]).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../include/picles_hip.h"
+
+#ifdef PO_PMATH
+#include "../picles_amd/csrc/pmath.h"
+#define o_exp pm_exp
+#define o_log pm_log
+#define o_pow pm_pow
+#define o_tanh pm_tanh
+#define o_cosh pm_cosh
+static inline double o_log10(double x) { return pm_log(x) * 0.43429448190325182765; }
+static inline double o_exp10(double x) { return pm_exp(x * 2.30258509299404568402); }
+#define PO_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#define o_exp exp
+#define o_log log
+#define o_pow pow
+#define o_tanh tanh
+#define o_cosh cosh
+static inline double o_log10(double x) { return log10(x); }
+static inline double o_exp10(double x) { return pow(10.0, x); }
+#define PO_FMA(a, b, c) fma((a), (b), (c))
+#endif
+
+#define PO_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * constants
+ * ---------------------------------------------------------------------------------------- */
+#define G0 9.81 /* hard default of c_g_conversions_vector, particle_waves_v5.jl:281-287 */
+
+/* Dormand-Prince 5(4) tableau (OrdinaryDiffEq DP5 == scipy.integrate RK45 A,B,C,E) */
+static const double A21 = 1.0 / 5.0;
+static const double A31 = 3.0 / 40.0, A32 = 9.0 / 40.0;
+static const double A41 = 44.0 / 45.0, A42 = -56.0 / 15.0, A43 = 32.0 / 9.0;
+static const double A51 = 19372.0 / 6561.0, A52 = -25360.0 / 2187.0, A53 = 64448.0 / 6561.0,
+                    A54 = -212.0 / 729.0;
+static const double A61 = 9017.0 / 3168.0, A62 = -355.0 / 33.0, A63 = 46732.0 / 5247.0,
+                    A64 = 49.0 / 176.0, A65 = -5103.0 / 18656.0;
+static const double A71 = 35.0 / 384.0, A73 = 500.0 / 1113.0, A74 = 125.0 / 192.0,
+                    A75 = -2187.0 / 6784.0, A76 = 11.0 / 84.0;
+static const double C2 = 1.0 / 5.0, C3 = 3.0 / 10.0, C4 = 4.0 / 5.0, C5 = 8.0 / 9.0;
+static const double E1 = -71.0 / 57600.0, E3 = 71.0 / 16695.0, E4 = -71.0 / 1920.0,
+                    E5 = 17253.0 / 339200.0, E6 = -22.0 / 525.0, E7 = 1.0 / 40.0;
+
+/* OrdinaryDiffEq PI controller defaults for DP5 (alg_utils.jl: beta2 = 4//100,
+ * beta1 = 1//5 - 3beta2/4, gamma = 9//10, qmin = 1//5, qmax = 10, qoldinit = 1//10^4) */
+#define CTRL_BETA1 0.17
+#define CTRL_BETA2 0.04
+#define CTRL_GAMMA 0.9
+#define CTRL_QMIN 0.2
+#define CTRL_QMAX 10.0
+#define CTRL_QOLDINIT 1e-4
+
+typedef struct po_consts {
+    double p, n, e_T, inv_eT, inv_rg, inv_dx, inv_dy;
+} po_consts;
+
+typedef struct po_model {
+    picles_grid g;
+    picles_phys ph;
+    picles_ode od;
+    picles_model md;
+    po_consts k;
+    int order;
+    int nthreads;
+    int Nx, Ny;
+    int64_t N;
+    int8_t *mask;
+    double *state, *movie;     /* 3 planes */
+    double *z;                 /* 5 planes */
+    double *qold, *dtn;        /* controller memory, next dt (<0: auto_dt_reset!) */
+    uint8_t *on, *bnd;
+    int32_t *status;
+    int64_t n_step;
+    int64_t *steplist;         /* ocean_points in reference order */
+    double *u0, *v0, *u1, *v1;
+    double tw0, tw1;
+    int wind_static;
+    double clock;
+    picles_counters cnt;
+    char err[256];
+} po_model;
+
+/* ------------------------------------------------------------------------------------------
+ * derived constants: magic_fractions (particle_waves_v5.jl:87-92), e_T_func (:271)
+ * ---------------------------------------------------------------------------------------- */
+static void po_derive(const picles_phys *ph, double dx, double dy, po_consts *k)
+{
+    double q = ph->q;
+    k->p = (-1.0 - 10.0 * q) / 2.0;
+    k->n = 2.0 * q / (k->p + 4.0 * q);
+    /* e_T = sqrt(c_e * c_α^(-p/q) / (γ*c_β*c_D)^(1/n)) */
+    k->e_T = sqrt(ph->c_e * o_pow(ph->c_alpha, -k->p / q) /
+                  o_pow(ph->gamma * ph->c_beta * ph->c_D, 1.0 / k->n));
+    k->inv_eT = 1.0 / k->e_T;
+    k->inv_rg = 1.0 / ph->r_g;
+    k->inv_dx = 1.0 / dx; /* ProjetionKernel: M = [1/dx 0; 0 1/dy], CartesianGrid.jl:115-121 */
+    k->inv_dy = 1.0 / dy;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FetchRelations.get_initial_windsea(U10,V10,time_scale; particle_state=true)
+ * FetchRelations.jl:314-359 with X_tilde_from_tau :128-130, fₘ_from_X_tilde :165-167,
+ * alpha_j :184-186, E_JONSWAP :201-203.
+ * ---------------------------------------------------------------------------------------- */
+static void po_windsea(double U10, double V10, double T, double out[3])
+{
+    const double A = 22.8013, xi0 = 2.4097, qx = 0.2748; /* Dulov_fetch_constants :107-111 */
+    double Ua = sqrt(U10 * U10 + V10 * V10);
+    Ua = (Ua < 0.1) ? 0.1 : Ua;
+    T = fabs(T);
+    double tau = 9.81 * T / fabs(Ua);
+    double X = o_pow(tau / (A * xi0), 1.0 / (1.0 - qx));
+    double fm = 3.5 * (9.81 / Ua) * o_pow(X, -0.33);
+    double aj = 0.033 * o_pow(fm * Ua / 9.81, 0.67);
+    double w = fm * 2.0 * M_PI;
+    double wi = 1.0 / w;
+    double E = 0.31 * (9.81 * 9.81) * aj * ((wi * wi) * (wi * wi));
+    double f_peak = fm * 9.81 / Ua;
+    double T_bar = 0.9 * (1.0 / f_peak);
+    double cg = 9.81 * T_bar / (4.0 * M_PI);
+    out[0] = o_log(E);
+    out[1] = cg * U10 / Ua;
+    out[2] = cg * V10 / Ua;
+}
+
+/* ResetParticleValues (core_2D.jl:307-343) / InitParticleValues default branch: the state a
+ * re-seeded particle gets at relative position (0,0) */
+static void po_reseed(const po_model *M, double u, double v, double T, double z[5])
+{
+    if (M->md.init_type == 0) {
+        double s[3];
+        po_windsea(u, v, T, s);
+        z[0] = s[0]; z[1] = s[1]; z[2] = s[2];
+    } else {
+        z[0] = M->md.default_particle[0];
+        z[1] = M->md.default_particle[1];
+        z[2] = M->md.default_particle[2];
+    }
+    z[3] = 0.0;
+    z[4] = 0.0;
+}
+
+/* GetParticleEnergyMomentum (core_2D.jl:69-78): m = c̄ e / |c̄|² / 2 */
+static void po_particle_to_charge(const double z[5], double c[3])
+{
+    double e = o_exp(z[0]);
+    double sp = sqrt(z[1] * z[1] + z[2] * z[2]);
+    c[0] = e;
+    c[1] = z[1] * e / (sp * sp) / 2.0;
+    c[2] = z[2] * e / (sp * sp) / 2.0;
+}
+
+/* GetVariablesAtVertex (core_2D.jl:121-128) */
+static void po_charge_to_particle(const double c[3], double z[5])
+{
+    double e = c[0], mx = c[1], my = c[2];
+    double ma = sqrt(mx * mx + my * my);
+    z[0] = o_log(e);
+    z[1] = mx * e / (2.0 * (ma * ma));
+    z[2] = my * e / (2.0 * (ma * ma));
+    z[3] = 0.0;
+    z[4] = 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * RHS — particle_system(dz,z,params,t), particle_waves_v5.jl:479-556 (Cartesian: PC ≡ 0)
+ * ---------------------------------------------------------------------------------------- */
+static void po_rhs_literal(const po_model *M, const double z[5], double u, double v, double dz[5])
+{
+    const picles_phys *ph = &M->ph;
+    const po_consts *k = &M->k;
+    double lne = z[0], cx = z[1], cy = z[2];
+    double r_g = ph->r_g;
+
+    double cbar = sqrt(cx * cx + cy * cy);                 /* speed() :297 */
+    double U = sqrt(u * u + v * v);
+    /* c_g_conversions_vector(abs(c̄), r_g) :281-287 (g = 9.81 hard default) */
+    double cgp = fabs(cbar) / r_g;
+    double cgp2 = cgp * cgp;
+    double kp = G0 / (4.0 * (cgp2 > 1e-2 ? cgp2 : 1e-2));
+    double acg = fabs(cgp);
+    double wp = G0 / (2.0 * (acg > 0.1 ? acg : 0.1));
+    double gx = cx / r_g, gy = cy / r_g;                   /* c_g_conversions :289-295 */
+    /* α_func :215-218 */
+    double a = U / (2.0 * cgp);
+    double alpha = (a > 500.0) ? 500.0 : a;
+    /* αₚ :212 */
+    double sg = sqrt(gx * gx + gy * gy);
+    double sgm = (sg > 1e-4) ? sg : 1e-4;
+    double ap = (u * gx + v * gy) / (2.0 * (sgm * sgm));
+    /* H_β :274, Δ_β :275 */
+    double H = 0.5 * (1.0 + o_tanh(k->p * (ap - 0.85)));
+    double sech = 1.0 / o_cosh(10.0 * (ap - 0.85));
+    double D = 1.0 - 1.25 * (sech * sech);
+
+    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0;
+    if (ph->input) It = ph->C_e * H * (alpha * alpha);        /* Ĩ_func :317-321 */
+    if (ph->dissipation) {                                 /* D̃_func_lne :331-335 */
+        double t = kp / k->e_T;
+        double pw = (2.0 * k->n == 4.0) ? (t * t) * (t * t) : o_pow(t, 2.0 * k->n);
+        Dt = o_exp(k->n * lne) * pw;
+    }
+    if (ph->peak_shift)                                    /* S_cg :340 */
+        Scg = ph->C_alpha * D * ((kp * kp) * (kp * kp)) * o_exp(2.0 * lne);
+    if (ph->direction) {                                   /* S_dir :345-346, sin2_a_min_b :242-249 */
+        double a2 = U / (2.0 * sg);
+        a2 = (a2 > 500.0) ? 500.0 : a2;
+        double UG = U * sg;
+        double s2;
+        if (UG == 0.0)
+            s2 = 0.0;
+        else
+            s2 = (2.0 / (UG * UG)) *
+                 (u * v * (2.0 * (gy * gy) - sg * sg) - gx * gy * (2.0 * (v * v) - U * U));
+        Sd = a2 * a2 * ph->C_phi * H * s2;
+    }
+    dz[0] = wp * r_g * Scg + wp * (It - Dt);               /* :526 */
+    dz[1] = -cx * wp * r_g * Scg + cy * Sd;                /* :529 */
+    dz[2] = -cy * wp * r_g * Scg - cx * Sd;                /* :530 */
+    if (ph->propagation) {                                 /* :536, M = diag(1/dx,1/dy) */
+        dz[3] = k->inv_dx * cx;
+        dz[4] = k->inv_dy * cy;
+    } else {
+        dz[3] = 0.0;
+        dz[4] = 0.0;
+    }
+}
+
+/* KERNEL order: the same RHS as the HIP kernels evaluate it (DESIGN.md "Kernel order").
+ * One reciprocal 1/c_gp feeds k_p, ω_p, α, α_p and sin2; |g| is taken as c_gp (identical in
+ * exact arithmetic); sin 2(θ_c-θ_w) is evaluated as 2·cross·dot/(U|g|)² (algebraically equal to
+ * sin2_a_min_b :242-249, exactly zero for aligned vectors); H_β via the logistic function,
+ * sech² via one exp; fused multiply-adds written out. */
+static void po_rhs_kernel(const po_model *M, const double z[5], double u, double v, double dz[5])
+{
+    const picles_phys *ph = &M->ph;
+    const po_consts *k = &M->k;
+    double lne = z[0], cx = z[1], cy = z[2];
+    double c2 = PO_FMA(cx, cx, cy * cy);
+    double cbar = sqrt(c2);
+    double U2 = PO_FMA(u, u, v * v);
+    double U = sqrt(U2);
+    double cgp = cbar * k->inv_rg;
+    double rc = 1.0 / cgp;
+    double minv = (cgp >= 0.1) ? rc : 10.0;
+    double wp = (0.5 * G0) * minv;
+    double kp = (0.25 * G0) * (minv * minv);
+    double a = (0.5 * U) * rc;
+    double alpha = (a > 500.0) ? 500.0 : a;
+    double gx = cx * k->inv_rg, gy = cy * k->inv_rg;
+    double dot = PO_FMA(u, gx, v * gy);
+    double crs = u * gy - v * gx;
+    double rc2 = rc * rc;
+    double sginv2 = (cgp >= 1e-4) ? rc2 : 1e8;
+    double ap = (0.5 * dot) * sginv2;
+    double ya = ap - 0.85;
+    double H = 1.0 / (1.0 + o_exp((-2.0 * k->p) * ya));
+    double t = o_exp(-20.0 * fabs(ya));
+    double t1 = 1.0 + t;
+    double D = 1.0 - (5.0 * t) / (t1 * t1);
+
+    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0;
+    double E2 = 0.0;
+    int n_is_2 = (k->n == 2.0);
+    if ((ph->dissipation && n_is_2) || ph->peak_shift) E2 = o_exp(2.0 * lne);
+    if (ph->input) It = (ph->C_e * H) * (alpha * alpha);
+    if (ph->dissipation) {
+        double ke = kp * k->inv_eT;
+        if (n_is_2) {
+            double ke2 = ke * ke;
+            Dt = E2 * (ke2 * ke2);
+        } else {
+            Dt = o_exp(k->n * lne) * o_pow(ke, 2.0 * k->n);
+        }
+    }
+    if (ph->peak_shift) {
+        double k2 = kp * kp;
+        Scg = ((ph->C_alpha * D) * (k2 * k2)) * E2;
+    }
+    if (ph->direction) {
+        double s2;
+        if (U == 0.0 || cgp == 0.0)
+            s2 = 0.0;
+        else
+            s2 = ((2.0 * crs) * dot) * (rc2 * (1.0 / U2));
+        Sd = (((alpha * alpha) * ph->C_phi) * H) * s2;
+    }
+    double wrS = (wp * ph->r_g) * Scg;
+    dz[0] = PO_FMA(wp, It - Dt, wrS);
+    dz[1] = PO_FMA(cy, Sd, -(cx * wrS));
+    dz[2] = -PO_FMA(cx, Sd, cy * wrS);
+    if (ph->propagation) {
+        dz[3] = cx * k->inv_dx;
+        dz[4] = cy * k->inv_dy;
+    } else {
+        dz[3] = 0.0;
+        dz[4] = 0.0;
+    }
+}
+
+static inline void po_rhs(const po_model *M, const double z[5], double u, double v, double dz[5])
+{
+    if (M->order == 0) po_rhs_literal(M, z, u, v, dz);
+    else po_rhs_kernel(M, z, u, v, dz);
+}
+
+/* node wind at absolute time t: the boundary's replacement of the closures u(x,y,t), v(x,y,t)
+ * (particle_waves_v5.jl:494-495): linear in t between two node-sampled levels. */
+static inline void po_wind(const po_model *M, int64_t idx, double t, double *u, double *v)
+{
+    if (M->wind_static) {
+        *u = M->u0[idx];
+        *v = M->v0[idx];
+        return;
+    }
+    if (M->order == 0) {
+        double s = (t - M->tw0) / (M->tw1 - M->tw0);
+        *u = M->u0[idx] + (M->u1[idx] - M->u0[idx]) * s;
+        *v = M->v0[idx] + (M->v1[idx] - M->v0[idx]) * s;
+    } else {
+        double s = (t - M->tw0) * (1.0 / (M->tw1 - M->tw0));
+        *u = PO_FMA(M->u1[idx] - M->u0[idx], s, M->u0[idx]);
+        *v = PO_FMA(M->v1[idx] - M->v0[idx], s, M->v0[idx]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Time integration: step!(integrator, DT, true) (call site mapping_2D.jl:152).
+ * Third-party semantics (OrdinaryDiffEq.jl v6, unpinned): DP5 perform_step!, ODE_DEFAULT_NORM
+ * (RMS), calculate_residuals, PIController, ode_determine_initdt, fix_dt_at_bounds!,
+ * modify_dt_for_tstops!.  See SURVEY.md Appendix C.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct po_pstats {
+    uint64_t rhs, acc, rej;
+    int status;
+} po_pstats;
+
+static inline double po_norm5_lit(const double a[5])
+{
+    double s = 0.0;
+    for (int i = 0; i < 5; i++) s += a[i] * a[i];
+    return sqrt(s / 5.0);
+}
+static inline double po_norm5_k(const double a[5])
+{
+    double s = a[0] * a[0];
+    for (int i = 1; i < 5; i++) s = PO_FMA(a[i], a[i], s);
+    return sqrt(s * 0.2);
+}
+
+/* ode_determine_initdt (OrdinaryDiffEq initdt.jl, out-of-place form), = auto_dt_reset!
+ * (mapping_2D.jl:95,103,110).  f0 = f(u0,t) is passed in (it is also the FSAL k1). */
+static double po_initdt(const po_model *M, int64_t idx, const double u0[5], const double f0[5],
+                        double t, po_pstats *st)
+{
+    const picles_ode *od = &M->od;
+    double sk[5], a0[5], a1[5];
+    int K = M->order;
+    for (int i = 0; i < 5; i++) {
+        sk[i] = K ? PO_FMA(fabs(u0[i]), od->reltol, od->abstol) : od->abstol + fabs(u0[i]) * od->reltol;
+        a0[i] = u0[i] / sk[i];
+        a1[i] = f0[i] / sk[i];
+    }
+    double d0 = K ? po_norm5_k(a0) : po_norm5_lit(a0);
+    double d1 = K ? po_norm5_k(a1) : po_norm5_lit(a1);
+    double dt0;
+    if (d0 < 1e-5 || d1 < 1e-5) dt0 = 1e-6;
+    else dt0 = K ? 0.01 * (d0 / d1) : (d0 / d1) / 100.0;
+    if (dt0 < 10.0 * 2.220446049250313e-16) return 1e-6;
+    double u1[5], f1[5], uw, vw;
+    for (int i = 0; i < 5; i++) u1[i] = K ? PO_FMA(dt0, f0[i], u0[i]) : u0[i] + dt0 * f0[i];
+    po_wind(M, idx, t + dt0, &uw, &vw);
+    po_rhs(M, u1, uw, vw, f1);
+    st->rhs++;
+    for (int i = 0; i < 5; i++) a1[i] = (f1[i] - f0[i]) / sk[i];
+    double d2 = (K ? po_norm5_k(a1) : po_norm5_lit(a1)) / dt0;
+    double m = (d1 > d2) ? d1 : d2;
+    double dt1;
+    if (m <= 1e-15) {
+        double c = dt0 * 1e-3;
+        dt1 = (1e-6 > c) ? 1e-6 : c;
+    } else {
+        dt1 = K ? o_exp10((2.0 + o_log10(m)) * -0.2) : o_exp10(-(2.0 + o_log10(m)) / 5.0);
+    }
+    double h = 100.0 * dt0;
+    if (dt1 < h) h = dt1;
+    /* a NaN estimate (non-finite f) must not poison dt: fall back to the smallest step */
+    if (!(h == h)) h = 1e-6;
+    return (od->dtmin > h) ? od->dtmin : h;
+}
+
+/* One attempted DP5 step of size h from (u0,k1) at absolute time t. Returns EEst. */
+static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], const double k1[5],
+                         double t, double h, double unew[5], double k7[5], po_pstats *st)
+{
+    const picles_ode *od = &M->od;
+    double k2[5], k3[5], k4[5], k5[5], k6[5], g[5], uw, vw;
+    int K = M->order;
+#define STAGE(expr_lit, expr_k) for (int i = 0; i < 5; i++) g[i] = K ? (expr_k) : (expr_lit)
+    if (!K) {
+        double a = h * A21;
+        for (int i = 0; i < 5; i++) g[i] = u0[i] + a * k1[i];
+    } else {
+        double a = h * A21;
+        for (int i = 0; i < 5; i++) g[i] = PO_FMA(a, k1[i], u0[i]);
+    }
+    po_wind(M, idx, K ? PO_FMA(C2, h, t) : t + C2 * h, &uw, &vw);
+    po_rhs(M, g, uw, vw, k2);
+    STAGE(u0[i] + h * (A31 * k1[i] + A32 * k2[i]),
+          PO_FMA(h, PO_FMA(A32, k2[i], A31 * k1[i]), u0[i]));
+    po_wind(M, idx, K ? PO_FMA(C3, h, t) : t + C3 * h, &uw, &vw);
+    po_rhs(M, g, uw, vw, k3);
+    STAGE(u0[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]),
+          PO_FMA(h, PO_FMA(A43, k3[i], PO_FMA(A42, k2[i], A41 * k1[i])), u0[i]));
+    po_wind(M, idx, K ? PO_FMA(C4, h, t) : t + C4 * h, &uw, &vw);
+    po_rhs(M, g, uw, vw, k4);
+    STAGE(u0[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]),
+          PO_FMA(h, PO_FMA(A54, k4[i], PO_FMA(A53, k3[i], PO_FMA(A52, k2[i], A51 * k1[i]))), u0[i]));
+    po_wind(M, idx, K ? PO_FMA(C5, h, t) : t + C5 * h, &uw, &vw);
+    po_rhs(M, g, uw, vw, k5);
+    STAGE(u0[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]),
+          PO_FMA(h, PO_FMA(A65, k5[i], PO_FMA(A64, k4[i], PO_FMA(A63, k3[i], PO_FMA(A62, k2[i], A61 * k1[i])))), u0[i]));
+    po_wind(M, idx, t + h, &uw, &vw);
+    po_rhs(M, g, uw, vw, k6);
+    for (int i = 0; i < 5; i++)
+        unew[i] = K ? PO_FMA(h, PO_FMA(A76, k6[i], PO_FMA(A75, k5[i], PO_FMA(A74, k4[i], PO_FMA(A73, k3[i], A71 * k1[i])))), u0[i])
+                    : u0[i] + h * (A71 * k1[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+    po_rhs(M, unew, uw, vw, k7);
+    st->rhs += 6;
+#undef STAGE
+    double at[5];
+    for (int i = 0; i < 5; i++) {
+        double ut, m0 = fabs(u0[i]), m1 = fabs(unew[i]);
+        double mm = (m0 > m1) ? m0 : m1;
+        if (!K) {
+            ut = h * (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k7[i]);
+            at[i] = ut / (od->abstol + mm * od->reltol);
+        } else {
+            ut = h * PO_FMA(E7, k7[i], PO_FMA(E6, k6[i], PO_FMA(E5, k5[i], PO_FMA(E4, k4[i], PO_FMA(E3, k3[i], E1 * k1[i])))));
+            at[i] = ut / PO_FMA(mm, od->reltol, od->abstol);
+        }
+    }
+    return K ? po_norm5_k(at) : po_norm5_lit(at);
+}
+
+/* step!(integrator, DT, true): integrate particle idx from clock to clock+DT. */
+static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qold, double *dtn,
+                         double t_start, double DT, po_pstats *st)
+{
+    const picles_ode *od = &M->od;
+    double k1[5], k7[5], unew[5], uw, vw;
+    double tr = 0.0; /* time since t_start; absolute time = t_start + tr */
+    po_wind(M, idx, t_start, &uw, &vw);
+    po_rhs(M, z, uw, vw, k1);
+    st->rhs++;
+    double dt = *dtn;
+    if (!(dt > 0.0)) dt = po_initdt(M, idx, z, k1, t_start, st);
+    int64_t iter = 0;
+    while (tr < DT) {
+        iter++;
+        if (iter > od->maxiters) { st->status |= PICLES_ST_MAXITERS; break; }
+        /* fix_dt_at_bounds!: dt >= max(eps(t), dtmin);  modify_dt_for_tstops!: dt <= tstop - t */
+        if (dt < od->dtmin) dt = od->dtmin;
+        double rem = DT - tr;
+        double h = (dt < rem) ? dt : rem;
+        int last = !(dt < rem);
+        double EEst = po_dp5_try(M, idx, z, k1, t_start + tr, h, unew, k7, st);
+        if (!(EEst == EEst)) { EEst = INFINITY; st->status |= PICLES_ST_NONFINITE; }
+        /* stepsize_controller!(PIController) */
+        double q11 = 0.0, q;
+        if (EEst == 0.0) {
+            q = 1.0 / CTRL_QMAX;
+        } else {
+            q11 = o_pow(EEst, CTRL_BETA1);
+            q = q11 / o_pow(*qold, CTRL_BETA2);
+            double qg = q / CTRL_GAMMA;
+            double lo = 1.0 / CTRL_QMAX, hi = 1.0 / CTRL_QMIN;
+            q = (qg < hi) ? qg : hi;
+            q = (q > lo) ? q : lo;
+        }
+        int accept = (EEst <= 1.0) || (od->force_dtmin && h <= od->dtmin);
+        if (accept) {
+            st->acc++;
+            *qold = (EEst > CTRL_QOLDINIT) ? EEst : CTRL_QOLDINIT; /* step_accept_controller! */
+            dt = h / q;
+            for (int i = 0; i < 5; i++) { z[i] = unew[i]; k1[i] = k7[i]; }
+            tr = last ? DT : tr + h;
+            /* unstable_check: NaN in u stops the integration (retcode Unstable) */
+            if (z[0] != z[0] || z[1] != z[1] || z[2] != z[2] || z[3] != z[3] || z[4] != z[4]) break;
+        } else {
+            st->rej++;
+            double f = q11 / CTRL_GAMMA;          /* step_reject_controller! */
+            double hi = 1.0 / CTRL_QMIN;
+            dt = h / ((f < hi) ? f : hi);
+            if (!od->force_dtmin && h <= od->dtmin) { st->status |= PICLES_ST_DTMIN; break; }
+        }
+    }
+    *dtn = dt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ParticleInCell: get_absolute_i_and_w(z, i_node) (ParticleInCell.jl:58-71),
+ * compute_weights_and_index_mininal (:149-157), construct_loop (:504-508),
+ * push_to_grid! AbstractBoundary method (:341-376), wrap_index! (:444-454), test_domain (:464-466)
+ * Indices here are 0-based; the drop / wrap tests are the reference's shifted by one.
+ * ---------------------------------------------------------------------------------------- */
+static inline void po_index_weight(double zp, int32_t i_node, int64_t idx[2], double w[2])
+{
+    double b = floor(zp);
+    int64_t ib = (int64_t)b;
+    double wc = rint((zp - b) * 1e6) / 1e6; /* round(·, digits=6) */
+    idx[0] = ib + i_node;
+    idx[1] = ib + i_node + 1;
+    w[0] = 1.0 - wc;
+    w[1] = wc;
+}
+static inline int64_t po_wrap(int64_t i, int64_t N)
+{
+    int64_t r = i % N;
+    return (r < 0) ? r + N : r;
+}
+/* returns max |cell offset| of the 4 corners (the scatter "reach") */
+static int po_particle_to_node(po_model *M, int32_t i, int32_t j, const double z[5])
+{
+    if (!(isfinite(z[3]) && isfinite(z[4]))) return 0; /* Int(floor(NaN)) would throw in Julia */
+    int64_t xi[2], yi[2];
+    double xw[2], yw[2], c[3];
+    po_index_weight(z[3], i, xi, xw);
+    po_index_weight(z[4], j, yi, yw);
+    po_particle_to_charge(z, c);
+    static const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 0, 1, 1}; /* construct_loop order */
+    for (int k = 0; k < 4; k++) {
+        int64_t ii = xi[ox[k]], jj = yi[oy[k]];
+        if (!M->g.periodic_x && !(ii >= 0 && ii < M->Nx)) continue;
+        if (!M->g.periodic_y && !(jj >= 0 && jj < M->Ny)) continue;
+        ii = po_wrap(ii, M->Nx);
+        jj = po_wrap(jj, M->Ny);
+        double w = xw[ox[k]] * yw[oy[k]];
+        int64_t n = ii + (int64_t)M->Nx * jj;
+        M->state[n] += w * c[0];
+        M->state[n + M->N] += w * c[1];
+        M->state[n + 2 * M->N] += w * c[2];
+    }
+    int64_t r = 0, d;
+    d = llabs(xi[0] - i); if (d > r) r = d;
+    d = llabs(xi[1] - i); if (d > r) r = d;
+    d = llabs(yi[0] - j); if (d > r) r = d;
+    d = llabs(yi[1] - j); if (d > r) r = d;
+    return (int)r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * advance!(PI, S, Failed, Grid, winds, DT, lne_max, wind_min², periodic, defaults)
+ * mapping_2D.jl:118-243 — everything except the final ParticleToNode!, which the caller does
+ * afterwards in ocean_points order (identical sums: advance! never reads State).
+ * ---------------------------------------------------------------------------------------- */
+static void po_advance_particle(po_model *M, int64_t idx, double DT, po_pstats *st)
+{
+    double z[5];
+    for (int c = 0; c < 5; c++) z[c] = M->z[idx + c * M->N];
+    double t_start = M->clock;
+    int status = PICLES_ST_STEPPED;
+    if (M->on[idx]) {
+        po_pstats s = {0, 0, 0, 0};
+        po_integrate(M, idx, z, &M->qold[idx], &M->dtn[idx], t_start, DT, &s);
+        st->rhs += s.rhs; st->acc += s.acc; st->rej += s.rej;
+        status |= s.status;
+    } else {
+        double u, v;
+        po_wind(M, idx, t_start + DT, &u, &v);
+        if (u * u + v * v >= M->od.wind_min_squared) {       /* :172-185 */
+            po_reseed(M, u, v, DT, z);
+            M->dtn[idx] = -1.0;
+            M->on[idx] = 1;
+            status |= PICLES_ST_SWITCHED_ON;
+        }
+    }
+    if (isnan(z[0]) || isnan(z[1]) || isnan(z[2])) {          /* :196-211 */
+        double u, v;
+        po_wind(M, idx, t_start + DT, &u, &v);
+        po_reseed(M, u, v, DT, z);
+        M->dtn[idx] = -1.0;
+        status |= PICLES_ST_RESEED_NAN;
+    } else if (isinf(z[0]) || isinf(z[1]) || isinf(z[2])) {   /* :213-222 */
+        double u, v;
+        po_wind(M, idx, t_start, &u, &v);
+        po_reseed(M, u, v, DT, z);
+        M->dtn[idx] = -1.0;
+        status |= PICLES_ST_RESEED_INF;
+    } else if (z[0] > M->od.log_energy_maximum) {             /* :224-235 */
+        z[0] = M->od.log_energy_maximum;
+        M->dtn[idx] = -1.0;
+        status |= PICLES_ST_CLAMPED;
+    }
+    for (int c = 0; c < 5; c++) M->z[idx + c * M->N] = z[c];
+    M->status[idx] = status;
+}
+
+/* NodeToParticle! (mapping_2D.jl:279-356) via remesh! (:250-269) */
+static void po_remesh_particle(po_model *M, int64_t idx, double DT)
+{
+    double c[3] = {M->state[idx], M->state[idx + M->N], M->state[idx + 2 * M->N]};
+    double u, v;
+    po_wind(M, idx, M->clock, &u, &v);          /* winds at model.clock.time, before tick! */
+    int bnd = M->bnd[idx];
+    double z[5];
+    if (!bnd && (c[0] >= M->md.minimal_state[0]) &&
+        (c[1] * c[1] + c[2] * c[2] >= M->md.minimal_state[1])) {           /* A :306-312 */
+        po_charge_to_particle(c, z);
+        for (int k = 0; k < 5; k++) M->z[idx + k * M->N] = z[k];
+        M->dtn[idx] = -1.0;
+        M->on[idx] = 1;
+    } else if (u * u + v * v >= M->od.wind_min_squared) {                   /* B :328-336, C :338-344 */
+        po_reseed(M, u, v, DT, z);
+        for (int k = 0; k < 5; k++) M->z[idx + k * M->N] = z[k];
+        M->qold[idx] = CTRL_QOLDINIT;              /* reinit! resets the controller */
+        M->dtn[idx] = -1.0;
+        M->on[idx] = 1;
+        __atomic_fetch_add(&M->cnt.reseeds, 1, __ATOMIC_RELAXED);
+    } else {                                                                /* D :347-353 */
+        M->on[idx] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * model: WaveGrowth2D constructor pieces (WaveGrowthModels2D.jl:194-345), mask classes
+ * (mask_utils.jl:38-55), ocean_points (:256-270), check_boundary_point (core_2D.jl:360-366)
+ * ---------------------------------------------------------------------------------------- */
+PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *p, const picles_ode *o,
+                                       const picles_model *m, int32_t order, po_model **out)
+{
+    if (!g || !p || !o || !m || !out) return -1;
+    if (g->Nx < 2 || g->Ny < 2) return -2;
+    po_model *M = (po_model *)calloc(1, sizeof(po_model));
+    M->g = *g; M->ph = *p; M->od = *o; M->md = *m;
+    M->order = order;
+    M->nthreads = 1;
+    M->Nx = g->Nx; M->Ny = g->Ny;
+    M->N = (int64_t)g->Nx * g->Ny;
+    int64_t N = M->N;
+    po_derive(p, g->dx, g->dy, &M->k);
+    M->mask = (int8_t *)malloc(N);
+    if (g->mask) {
+        memcpy(M->mask, g->mask, N);
+    } else { /* make_boundaries(ones) : grid-boundary ring on non-periodic axes */
+        memset(M->mask, 1, N);
+        for (int j = 0; j < M->Ny; j++)
+            for (int i = 0; i < M->Nx; i++) {
+                int ring = (!g->periodic_x && (i == 0 || i == M->Nx - 1)) ||
+                           (!g->periodic_y && (j == 0 || j == M->Ny - 1));
+                if (ring) M->mask[i + (int64_t)M->Nx * j] = 3;
+            }
+    }
+    M->g.mask = M->mask;
+    M->state = (double *)calloc(3 * N, 8);
+    M->movie = (double *)calloc(3 * N, 8);
+    M->z = (double *)calloc(5 * N, 8);
+    M->qold = (double *)calloc(N, 8);
+    M->dtn = (double *)calloc(N, 8);
+    M->on = (uint8_t *)calloc(N, 1);
+    M->bnd = (uint8_t *)calloc(N, 1);
+    M->status = (int32_t *)calloc(N, 4);
+    M->u0 = (double *)calloc(N, 8); M->v0 = (double *)calloc(N, 8);
+    M->u1 = (double *)calloc(N, 8); M->v1 = (double *)calloc(N, 8);
+    M->wind_static = 1;
+    /* ocean_points: findall(mask .== 1) [then findall(mask .== 3) if periodic_boundary], column-major */
+    M->steplist = (int64_t *)malloc(N * 8);
+    int64_t ns = 0;
+    for (int64_t n = 0; n < N; n++) if (M->mask[n] == 1) M->steplist[ns++] = n;
+    if (m->periodic_boundary)
+        for (int64_t n = 0; n < N; n++) if (M->mask[n] == 3) M->steplist[ns++] = n;
+    M->n_step = ns;
+    for (int64_t n = 0; n < N; n++)
+        M->bnd[n] = m->periodic_boundary ? (M->mask[n] == 2) : (M->mask[n] >= 2);
+    *out = M;
+    return 0;
+}
+
+PO_EXPORT int32_t picles_oracle_destroy(po_model *M)
+{
+    if (!M) return 0;
+    free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->dtn);
+    free(M->on); free(M->bnd); free(M->status); free(M->steplist);
+    free(M->u0); free(M->v0); free(M->u1); free(M->v1);
+    free(M);
+    return 0;
+}
+
+PO_EXPORT int32_t picles_oracle_set_threads(po_model *M, int32_t n) { M->nthreads = n > 0 ? n : 1; return 0; }
+
+PO_EXPORT int32_t picles_oracle_set_winds(po_model *M, const double *u0, const double *v0, double t0,
+                                          const double *u1, const double *v1, double t1)
+{
+    memcpy(M->u0, u0, M->N * 8);
+    memcpy(M->v0, v0, M->N * 8);
+    M->tw0 = t0;
+    if (u1 && v1 && t1 != t0) {
+        memcpy(M->u1, u1, M->N * 8);
+        memcpy(M->v1, v1, M->N * 8);
+        M->tw1 = t1;
+        M->wind_static = 0;
+    } else {
+        M->wind_static = 1;
+        M->tw1 = t0;
+    }
+    return 0;
+}
+
+/* init_particles! (run.jl:199-247) -> SeedParticle (core_2D.jl:434-488) -> InitParticleValues
+ * (:247-288) -> init_z0_to_State! (initialize.jl:14-17) */
+PO_EXPORT int32_t picles_oracle_seed(po_model *M, double t0)
+{
+    int64_t N = M->N;
+    M->clock = t0;
+    memset(M->state, 0, 3 * N * 8);
+    memset(&M->cnt, 0, sizeof(M->cnt));
+    for (int64_t n = 0; n < N; n++) {
+        M->status[n] = 0;
+        M->qold[n] = CTRL_QOLDINIT;
+        M->dtn[n] = M->od.dt0;
+        for (int c = 0; c < 5; c++) M->z[n + c * N] = 0.0;
+        M->on[n] = 0;
+        if (M->mask[n] == 0) continue; /* land: dummy instance */
+        double u, v, z[5];
+        po_wind(M, n, 0.0 + (M->wind_static ? 0.0 : 0.0), &u, &v); /* winds at t = 0.0 (run.jl:213-215) */
+        int on;
+        if (M->md.init_type == 0) {
+            if (sqrt(u * u + v * v) > sqrt(2.0)) {
+                double s[3];
+                po_windsea(u, v, M->od.timestep, s);
+                z[0] = s[0]; z[1] = s[1]; z[2] = s[2];
+                on = 1;
+            } else {
+                /* MinimalParticle(u,v,DT): MinimalWindsea with rand_sign -> +1 */
+                double uu = (u == 0.0) ? 1.0 : u, vv = (v == 0.0) ? 1.0 : v;
+                double am = sqrt(uu * uu + vv * vv), s[3];
+                po_windsea(1.0 * uu / am, 1.0 * vv / am, M->od.timestep, s);
+                z[0] = s[0]; z[1] = s[1]; z[2] = s[2];
+                on = 0;
+            }
+        } else {
+            z[0] = M->md.default_particle[0];
+            z[1] = M->md.default_particle[1];
+            z[2] = M->md.default_particle[2];
+            on = 1;
+        }
+        z[3] = 0.0; z[4] = 0.0;
+        for (int c = 0; c < 5; c++) M->z[n + c * N] = z[c];
+        M->on[n] = (uint8_t)on;
+        if (on) {
+            double c3[3];
+            po_particle_to_charge(z, c3);
+            M->state[n] = c3[0];
+            M->state[n + N] = c3[1];
+            M->state[n + 2 * N] = c3[2];
+        }
+    }
+    return 0;
+}
+
+/* time_step!_advance (TimeSteppers.jl:168-180) */
+PO_EXPORT int32_t picles_oracle_advance(po_model *M, double DT)
+{
+    uint64_t rhs = 0, acc = 0, rej = 0, adv = 0;
+    int64_t ns = M->n_step;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(M->nthreads) reduction(+ : rhs, acc, rej, adv)
+#endif
+    for (int64_t s = 0; s < ns; s++) {
+        int64_t idx = M->steplist[s];
+        po_pstats st = {0, 0, 0, 0};
+        int was_on = M->on[idx];
+        po_advance_particle(M, idx, DT, &st);
+        rhs += st.rhs; acc += st.acc; rej += st.rej; adv += was_on ? 1 : 0;
+    }
+    M->cnt.rhs_evals += rhs; M->cnt.steps_accepted += acc; M->cnt.steps_rejected += rej;
+    M->cnt.particles_advanced += adv;
+    /* ParticleToNode! in ocean_points order (the sequential sum order IS the definition) */
+    int reach = 0;
+    for (int64_t s = 0; s < ns; s++) {
+        int64_t idx = M->steplist[s];
+        int st = M->status[idx];
+        if (st & (PICLES_ST_RESEED_NAN | PICLES_ST_RESEED_INF | PICLES_ST_SWITCHED_ON)) M->cnt.reseeds++;
+        if (st & PICLES_ST_CLAMPED) M->cnt.clamps++;
+        if (st & PICLES_ST_MAXITERS) M->cnt.maxiters_hits++;
+        if (!M->on[idx]) continue;
+        double z[5];
+        for (int c = 0; c < 5; c++) z[c] = M->z[idx + c * M->N];
+        int r = po_particle_to_node(M, (int32_t)(idx % M->Nx), (int32_t)(idx / M->Nx), z);
+        if (r > reach) reach = r;
+    }
+    M->cnt.max_reach = reach;
+    return 0;
+}
+
+/* time_step!_remesh (TimeSteppers.jl:182-193) */
+PO_EXPORT int32_t picles_oracle_remesh(po_model *M, double DT)
+{
+    int64_t ns = M->n_step;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(M->nthreads)
+#endif
+    for (int64_t s = 0; s < ns; s++) po_remesh_particle(M, M->steplist[s], DT);
+    return 0;
+}
+
+PO_EXPORT int32_t picles_oracle_zero_state(po_model *M) { memset(M->state, 0, 3 * M->N * 8); return 0; }
+PO_EXPORT int32_t picles_oracle_tick(po_model *M, double dt) { M->clock += dt; return 0; }
+PO_EXPORT double picles_oracle_clock(const po_model *M) { return M->clock; }
+
+/* time_step! (TimeSteppers.jl:109-166) / movie_time_step! (:212-247); flags as picles_time_step */
+PO_EXPORT int32_t picles_oracle_time_step(po_model *M, double dt, int32_t flags)
+{
+    if (flags & PICLES_STEP_ZERO_FIRST) picles_oracle_zero_state(M);
+    picles_oracle_advance(M, dt);
+    if (flags & PICLES_STEP_MOVIE) memcpy(M->movie, M->state, 3 * M->N * 8);
+    picles_oracle_remesh(M, dt);
+    if (flags & PICLES_STEP_MOVIE) picles_oracle_zero_state(M);
+    M->clock += dt;
+    return 0;
+}
+
+PO_EXPORT int32_t picles_oracle_get_state(po_model *M, double *s) { memcpy(s, M->state, 3 * M->N * 8); return 0; }
+PO_EXPORT int32_t picles_oracle_set_state(po_model *M, const double *s) { memcpy(M->state, s, 3 * M->N * 8); return 0; }
+PO_EXPORT int32_t picles_oracle_get_movie_state(po_model *M, double *s) { memcpy(s, M->movie, 3 * M->N * 8); return 0; }
+PO_EXPORT int32_t picles_oracle_get_particles(po_model *M, double *z, uint8_t *on, uint8_t *bnd, int32_t *status)
+{
+    if (z) memcpy(z, M->z, 5 * M->N * 8);
+    if (on) memcpy(on, M->on, M->N);
+    if (bnd) memcpy(bnd, M->bnd, M->N);
+    if (status) memcpy(status, M->status, M->N * 4);
+    return 0;
+}
+PO_EXPORT int32_t picles_oracle_set_particles(po_model *M, const double *z, const uint8_t *on)
+{
+    if (z) memcpy(M->z, z, 5 * M->N * 8);
+    if (on) memcpy(M->on, on, M->N);
+    for (int64_t n = 0; n < M->N; n++) M->dtn[n] = -1.0;
+    return 0;
+}
+PO_EXPORT int32_t picles_oracle_get_controller(po_model *M, double *qold, double *dtn)
+{
+    if (qold) memcpy(qold, M->qold, M->N * 8);
+    if (dtn) memcpy(dtn, M->dtn, M->N * 8);
+    return 0;
+}
+PO_EXPORT int32_t picles_oracle_get_counters(po_model *M, picles_counters *c) { *c = M->cnt; return 0; }
+PO_EXPORT int32_t picles_oracle_get_mask(po_model *M, int8_t *mask) { memcpy(mask, M->mask, M->N); return 0; }
+PO_EXPORT int64_t picles_oracle_n_stepped(po_model *M) { return M->n_step; }
+PO_EXPORT double picles_oracle_e_T(po_model *M) { return M->k.e_T; }
+
+/* ---- single-function entry points for unit tests ---------------------------------------- */
+PO_EXPORT void picles_oracle_windsea(double U, double V, double T, double out[3]) { po_windsea(U, V, T, out); }
+PO_EXPORT void picles_oracle_rhs(po_model *M, const double z[5], double u, double v, double dz[5]) { po_rhs(M, z, u, v, dz); }
+PO_EXPORT void picles_oracle_particle_to_charge(const double z[5], double c[3]) { po_particle_to_charge(z, c); }
+PO_EXPORT void picles_oracle_charge_to_particle(const double c[3], double z[5]) { po_charge_to_particle(c, z); }
+PO_EXPORT void picles_oracle_index_weight(double zp, int32_t i_node, int64_t idx[2], double w[2]) { po_index_weight(zp, i_node, idx, w); }
+/* integrate node idx's wind with an explicit start state over DT; returns rhs/acc/rej in stats[3] */
+PO_EXPORT int32_t picles_oracle_integrate(po_model *M, int64_t idx, double z[5], double *qold, double *dtn,
+                                          double t_start, double DT, uint64_t stats[3])
+{
+    po_pstats st = {0, 0, 0, 0};
+    po_integrate(M, idx, z, qold, dtn, t_start, DT, &st);
+    stats[0] = st.rhs; stats[1] = st.acc; stats[2] = st.rej;
+    return st.status;
+}
+PO_EXPORT int32_t picles_oracle_is_pmath(void)
+{
+#ifdef PO_PMATH
+    return 1;
+#else
+    return 0;
+#endif
+}
+PO_EXPORT int32_t picles_oracle_has_openmp(void)
+{
+#ifdef _OPENMP
+    return 1;
+#else
+    return 0;
+#endif
+}
+PO_EXPORT void picles_oracle_math(int32_t fn, int64_t n, const double *x, const double *y, double *out)
+{
+    for (int64_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: out[i] = o_exp(x[i]); break;
+        case 1: out[i] = o_log(x[i]); break;
+        case 2: out[i] = o_pow(x[i], y[i]); break;
+        case 3: out[i] = o_tanh(x[i]); break;
+        case 4: out[i] = o_cosh(x[i]); break;
+        case 5: out[i] = x[i] / y[i]; break;
+        case 6: out[i] = sqrt(x[i]); break;
+        default: out[i] = NAN;
+        }
+    }
+}

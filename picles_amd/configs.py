@@ -1,0 +1,123 @@
+"""The workloads of BASELINE.json `configs`, built through the reference-shaped host API.
+
+Each builder returns kwargs for WaveGrowth2D plus the stepping parameters
+(`Δt`, `n_steps`, `mode`), citing the reference script it restates."""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import fetch_relations as FetchRelations
+from .grids import TwoDCartesianGridMesh
+from .particle_waves_v5 import ODEParameters, ODESettings, particle_equations, IDConstants, ScgConstants
+
+MINUTES, HOURS, DAYS = 60.0, 3600.0, 86400.0
+
+
+def const_winds(U10, V10):
+    def u(x, y, t):
+        return U10 + 0 * x
+
+    def v(x, y, t):
+        return V10 + 0 * x
+    return SimpleNamespace(u=u, v=v)
+
+
+def example_00_minimal(n=51, L=100e3, U10=10.0, V10=10.0):
+    """examples/example_00_minimal.jl:18-67 — 51×51, 100 km box, winds (10,10), DT = 10 min,
+    run!(stop_time = 2 h) => 13 steps, non-periodic grid, periodic_boundary = false,
+    C_φ = 1.81e-5 (ODEParameters)."""
+    DT = 10 * MINUTES
+    winds = const_winds(U10, V10)
+    grid = TwoDCartesianGridMesh(L, n, L, n)
+    ODEpars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
+    psys = particle_equations(winds.u, winds.v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
+    ws = FetchRelations.MinimalWindsea(U10, V10, DT)
+    sets = ODESettings(Parameters=ODEpars, log_energy_minimum=ws["lne"], saving_step=DT, timestep=DT,
+                       total_time=6 * DAYS, dt=1e-3, dtmin=1e-4, force_dtmin=True)
+    return SimpleNamespace(
+        model=dict(grid=grid, winds=winds, ODEsys=psys, ODEsets=sets, periodic_boundary=False,
+                   minimal_particle=FetchRelations.MinimalParticle(U10, V10, DT), movie=True, winds_static=True),
+        Δt=DT, stop_time=2 * HOURS, n_steps=13, mode="run")
+
+
+def T04_2D_reg_test(n=31, L=120e3, U10=5.0, V10=5.0, periodic=False, n_steps=36):
+    """tests/T04_2D_reg_test.jl:40-151 — 4 km spacing, C_φ = c_β = 0.04 (:64-65),
+    movie_time_step! × 36, periodic ∈ {true,false} is the MODEL flag on a non-periodic grid.
+    BASELINE config 2 scales it to 256×256 (n=256, L=255*4000)."""
+    DT = 10 * MINUTES
+    winds = const_winds(U10, V10)
+    grid = TwoDCartesianGridMesh(L, n, L, n)
+    ODEpars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
+    psys = particle_equations(winds.u, winds.v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
+    pars = dict(r_g=0.85, C_α=Const_Scg.C_alpha, C_φ=Const_ID.c_β, C_e=Const_ID.C_e, g=9.81)
+    ws = FetchRelations.MinimalWindsea(U10, V10, DT)
+    sets = ODESettings(Parameters=pars, log_energy_minimum=ws["lne"], log_energy_maximum=math.log(17),
+                       saving_step=DT, timestep=DT, total_time=6 * DAYS, adaptive=True,
+                       dt=1e-3, dtmin=1e-4, force_dtmin=True)
+    return SimpleNamespace(
+        model=dict(grid=grid, winds=winds, ODEsys=psys, ODEsets=sets, ODEinit_type="wind_sea",
+                   periodic_boundary=periodic, boundary_type="same",
+                   minimal_particle=FetchRelations.MinimalParticle(U10, V10, DT), movie=True, winds_static=True),
+        Δt=DT, n_steps=n_steps, mode="movie")
+
+
+def bench06_box(n=1024, dx=2000.0, U10=10.0, V10=10.0, n_steps=100, periodic_grid=True):
+    """benchmark/bench06_homogenous_box_brenchmarlk.jl:47-126 scaled per BASELINE configs 3/4:
+    γ = 0.88 passed explicitly (:72), C_φ = c_β = 0.04 (:77), DP5, lne_max = log 27, dt0 = 10,
+    dtmin = 1, force_dtmin, seed time-scale 30 min (:49,96), model Δt = 10 min (:126); fully
+    periodic grid + periodic_boundary = true (BASELINE's choice; the file itself is non-periodic)."""
+    DT_seed = 30 * MINUTES
+    winds = const_winds(U10, V10)
+    L = dx * (n - 1)
+    grid = TwoDCartesianGridMesh(L, n, L, n, periodic_boundary=(periodic_grid, periodic_grid))
+    Const_ID = IDConstants.make()
+    Const_Scg = ScgConstants(C_alpha=-1.41, C_varphi=1.81e-5)
+    psys = particle_equations(winds.u, winds.v, γ=0.88, q=Const_ID.q, IDConstants=Const_ID, input=True, dissipation=True)
+    pars = dict(r_g=0.85, C_α=Const_Scg.C_alpha, C_φ=Const_ID.c_β, C_e=Const_ID.C_e, g=9.81)
+    ws = FetchRelations.MinimalWindsea(U10, V10, DT_seed)
+    sets = ODESettings(Parameters=pars, log_energy_minimum=math.log(ws["E"]), solver="DP5",
+                       log_energy_maximum=math.log(27), saving_step=6 * DAYS, timestep=DT_seed,
+                       total_time=6 * DAYS, adaptive=True, dt=10, dtmin=1, force_dtmin=True)
+    return SimpleNamespace(
+        model=dict(grid=grid, winds=winds, ODEsys=psys, ODEsets=sets, ODEinit_type="wind_sea",
+                   periodic_boundary=periodic_grid, boundary_type="same", movie=False, winds_static=True),
+        Δt=10 * MINUTES, n_steps=n_steps, mode="run")
+
+
+def box4096(n=4096, n_steps=50, **kw):
+    """BASELINE config 4: 4096×4096, dx = 2000 m, winds (10,10), periodic, physics as bench06."""
+    return bench06_box(n=n, n_steps=n_steps, **kw)
+
+
+def growing_decaying_winds(n=2048, dx=2000.0, U10=10.0, V10=10.0, n_steps=60):
+    """BASELINE config 5: ramp of tests/T04_2D_growing_decaying_winds.jl:131-132
+    (0.1 m/s below x0 = L/2, linear rise to U10 at x = L) times the time factor of
+    tests/T04_2D_reg_test.jl:167 cos(t·3/(3600·2π)) on u; DT = 20 min; physics as example_00
+    with lne_max = log 27.  Exercises off/re-seed branches and wave divergence."""
+    DT = 20 * MINUTES
+    L = dx * (n - 1)
+    x0 = L / 2
+
+    def ramp(x):
+        return np.where(x < x0, 0.1, (x - x0) / (L - x0))
+
+    def u(x, y, t):
+        return np.where(x < x0, 0.1, U10 * (x - x0) / (L - x0)) * np.cos(t * 3 / (3600 * 2 * np.pi))
+
+    def v(x, y, t):
+        return np.where(x < x0, 0.1, V10 * (x - x0) / (L - x0)) + 0 * t
+    winds = SimpleNamespace(u=u, v=v)
+    grid = TwoDCartesianGridMesh(L, n, L, n)
+    ODEpars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
+    psys = particle_equations(u, v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
+    ws = FetchRelations.MinimalWindsea(U10, V10, DT)
+    sets = ODESettings(Parameters=ODEpars, log_energy_minimum=ws["lne"], log_energy_maximum=math.log(27),
+                       saving_step=DT, timestep=DT, total_time=6 * DAYS, dt=1e-3, dtmin=1e-4, force_dtmin=True)
+    return SimpleNamespace(
+        model=dict(grid=grid, winds=winds, ODEsys=psys, ODEsets=sets, ODEinit_type="wind_sea",
+                   periodic_boundary=False, boundary_type="same",
+                   minimal_particle=FetchRelations.MinimalParticle(U10, V10, DT), movie=False, winds_static=False),
+        Δt=DT, n_steps=n_steps, mode="run")

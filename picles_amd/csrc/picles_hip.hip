@@ -1,0 +1,1087 @@
+/*
+ * picles_hip.hip — HIP kernels (gfx950 / CDNA4) and the C ABI of include/picles_hip.h.
+ *
+ * One context = one GPU = one y-slab of the 2D Cartesian mesh.  Particles are born at and
+ * return to their node every model step (mapping_2D.jl:279-356), so particle k IS node k:
+ * the particle SoA, the State planes and the cell list share one index (identity cell list).
+ *
+ * HBM layout (all fp64 unless noted; i fastest, local rows jl = j - j_begin):
+ *   state[3][n]      e, m_x, m_y planes              (reference State[Nx,Ny,3], col-major)
+ *   movie[3][n]      MovieState snapshot
+ *   z[5][n]          lne, c̄x, c̄y, x, y planes        (ParticleInstance2D.ODEIntegrator.u)
+ *   qold[n], dtn[n]  PI-controller memory, next dt (<0 => auto_dt_reset!)
+ *   on[n] u8, pflags[n] u8 (bit0 stepped, bit1 group-2 (mask 3), bit2 boundary), status[n] i32
+ *   wind u0,v0,u1,v1 [n]
+ *   rec[(ny_loc+2R)][6][Nx]   per-row scatter records e, m_x, m_y, x, y, flag of every particle
+ *                    (+R ghost rows per side = the halo blocks exchanged between slabs; a row
+ *                    block is contiguous, so halo send/recv need no pack/unpack)
+ *
+ * Kernels and the roofline that bounds each (DESIGN.md has the numbers):
+ *   k_advance        fused per-particle step: guards + DP5 adaptive RK of the 5-vector in
+ *                    registers + charge/record write.  fp64-VALU bound (~10^4..10^5 flop per
+ *                    particle-step against 136 B).  No MFMA: not a contraction.
+ *   k_scatter        deterministic PULL scatter (each node sums its <= (2R+1)^2 candidate
+ *                    sources in the reference's sequential order => bitwise reproducible),
+ *                    fused with State zero-fill, MovieState snapshot and remesh. HBM bound.
+ *   k_push_tiles     PUSH scatter: LDS-staged grid tile + apron, ds_add_f64 inside the tile,
+ *                    one global fp64 atomic per touched tile node. HBM/atomic bound.
+ *   k_remesh         stand-alone NodeToParticle! (split API).
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/picles_hip.h"
+#include "physics.h"
+
+#define PX_EXPORT extern "C" __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+struct GridP {
+    int Nx, Ny;            /* global */
+    int periodic_x, periodic_y;
+    int j_begin, ny_loc;
+    int R;                 /* scatter reach the pull kernel covers = ghost rows per side */
+    int single_slab;       /* this context owns all rows: wrap in y is local */
+    int ngroups;           /* 1, or 2 when grid-boundary (mask 3) particles are stepped */
+};
+
+struct DevCounters {
+    unsigned long long rhs, acc, rej, reseeds, clamps, maxit, adv, overflow;
+    int max_reach;
+    int pad;
+};
+
+struct Arrays {
+    double *state, *movie;   /* 3 planes */
+    double *z;               /* 5 planes */
+    double *qold, *dtn;
+    unsigned char *on, *pflags;
+    int *status;
+    double *u0, *v0, *u1, *v1;
+    double *rec;
+    DevCounters *cnt;
+    long long n;             /* Nx * ny_loc */
+};
+
+#define PF_STEPPED 1
+#define PF_GROUP2 2
+#define PF_BOUNDARY 4
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, 64);
+        v = (t > v) ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, long long t)
+{
+    Wind w;
+    w.u0 = A.u0[t];
+    w.v0 = A.v0[t];
+    if (P.wind_static) {
+        w.du = 0.0;
+        w.dv = 0.0;
+    } else {
+        w.du = A.u1[t] - w.u0;
+        w.dv = A.v1[t] - w.v0;
+    }
+    return w;
+}
+
+__device__ __forceinline__ double *rec_row(const Arrays &A, const GridP &G, int row)
+{
+    return A.rec + (size_t)row * 6 * G.Nx;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_seed — init_particles! / SeedParticle / InitParticleValues / init_z0_to_State!
+ * (run.jl:199-247, core_2D.jl:247-288,434-488, initialize.jl:14-17)
+ * ---------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, const signed char *mask, double seed_T)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= A.n) return;
+    int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
+    Vec5 z = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int on = 0;
+    double e = 0.0, mx = 0.0, my = 0.0;
+    if (mask[t] != 0) {
+        Wind w = load_wind(P, A, t);
+        double u, v;
+        wind_at(P, w, 0.0, u, v);   /* winds at t = 0.0 (run.jl:213-215) */
+        if (P.init_type == 0) {
+            if (__builtin_sqrt(u * u + v * v) > __builtin_sqrt(2.0)) {
+                seed_windsea(u, v, seed_T, z.lne, z.cx, z.cy);
+                on = 1;
+            } else {   /* MinimalParticle: unit-speed wind in the wind's direction (rand_sign -> +1) */
+                double uu = (u == 0.0) ? 1.0 : u, vv = (v == 0.0) ? 1.0 : v;
+                double am = __builtin_sqrt(uu * uu + vv * vv);
+                seed_windsea(1.0 * uu / am, 1.0 * vv / am, seed_T, z.lne, z.cx, z.cy);
+                on = 0;
+            }
+        } else {
+            z.lne = P.def_lne; z.cx = P.def_cx; z.cy = P.def_cy;
+            on = 1;
+        }
+        if (on) particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
+    }
+    A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
+    A.on[t] = (unsigned char)on;
+    A.qold[t] = PI_QOLDINIT;
+    A.dtn[t] = P.dt0;
+    A.status[t] = 0;
+    A.state[t] = e; A.state[t + A.n] = mx; A.state[t + 2 * A.n] = my;
+    double *rr = rec_row(A, G, jl + G.R);
+    rr[5 * G.Nx + i] = 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_advance — advance! (mapping_2D.jl:118-243) for the particles of local rows
+ * [r0, r0+n0) ∪ [r1, r1+n1).  One thread per particle; the whole adaptive RK loop runs in
+ * registers.  Writes the particle's scatter record (ParticleToNode! inputs) instead of
+ * scattering: the scatter itself is k_scatter / k_push_tiles.
+ * ---------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
+                                                   int r0, int n0, int r1, int n1)
+{
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
+    bool active = tid < na + nb;
+    long long t = 0;
+    if (active) t = (tid < na) ? (long long)r0 * G.Nx + tid : (long long)r1 * G.Nx + (tid - na);
+    unsigned char pf = active ? A.pflags[t] : 0;
+    active = active && (pf & PF_STEPPED);
+
+    PStats st = {0u, 0u, 0u, 0};
+    unsigned int adv = 0, reseeds = 0, clamps = 0, maxit = 0, overflow = 0;
+    int reach = 0;
+    if (active) {
+        int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
+        Vec5 z;
+        z.lne = A.z[t]; z.cx = A.z[t + A.n]; z.cy = A.z[t + 2 * A.n]; z.x = A.z[t + 3 * A.n]; z.y = A.z[t + 4 * A.n];
+        int on = A.on[t];
+        double qold = A.qold[t], dtn = A.dtn[t];
+        Wind w = load_wind(P, A, t);
+        int status = PICLES_ST_STEPPED;
+        if (on) {
+            adv = 1;
+            integrate_dp5(P, w, z, qold, dtn, t_start, DT, st);
+            status |= st.status;
+        } else {
+            double u, v;
+            wind_at(P, w, t_start + DT, u, v);
+            if (u * u + v * v >= P.wind_min_sq) {
+                reseed(P, u, v, DT, z);
+                dtn = -1.0;
+                on = 1;
+                status |= PICLES_ST_SWITCHED_ON;
+            }
+        }
+        if (pm_isnan(z.lne) || pm_isnan(z.cx) || pm_isnan(z.cy)) {
+            double u, v;
+            wind_at(P, w, t_start + DT, u, v);
+            reseed(P, u, v, DT, z);
+            dtn = -1.0;
+            status |= PICLES_ST_RESEED_NAN;
+        } else if (pm_isinf(z.lne) || pm_isinf(z.cx) || pm_isinf(z.cy)) {
+            double u, v;
+            wind_at(P, w, t_start, u, v);
+            reseed(P, u, v, DT, z);
+            dtn = -1.0;
+            status |= PICLES_ST_RESEED_INF;
+        } else if (z.lne > P.lne_max) {
+            z.lne = P.lne_max;
+            dtn = -1.0;
+            status |= PICLES_ST_CLAMPED;
+        }
+        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
+        A.on[t] = (unsigned char)on;
+        A.qold[t] = qold;
+        A.dtn[t] = dtn;
+        A.status[t] = status;
+        if (status & (PICLES_ST_RESEED_NAN | PICLES_ST_RESEED_INF | PICLES_ST_SWITCHED_ON)) reseeds = 1;
+        if (status & PICLES_ST_CLAMPED) clamps = 1;
+        if (status & PICLES_ST_MAXITERS) maxit = 1;
+        /* scatter record */
+        double *rr = rec_row(A, G, jl + G.R);
+        double flag = 0.0;
+        if (on && pm_isfinite(z.x) && pm_isfinite(z.y)) {
+            double e, mx, my;
+            particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
+            rr[i] = e; rr[G.Nx + i] = mx; rr[2 * G.Nx + i] = my; rr[3 * G.Nx + i] = z.x; rr[4 * G.Nx + i] = z.y;
+            flag = (pf & PF_GROUP2) ? 2.0 : 1.0;
+            int bx, by;
+            double wx, wy;
+            index_weight(z.x, bx, wx);
+            index_weight(z.y, by, wy);
+            int r = (bx < 0) ? -bx : bx + 1;
+            int ry = (by < 0) ? -by : by + 1;
+            reach = (r > ry) ? r : ry;
+            if (reach > G.R) overflow = 1;
+        }
+        rr[5 * G.Nx + i] = flag;
+    }
+    /* counters: wave-reduce, one atomic per wave */
+    unsigned long long s_rhs = wave_sum_u64(st.rhs), s_acc = wave_sum_u64(st.acc), s_rej = wave_sum_u64(st.rej);
+    unsigned long long s_adv = wave_sum_u64(adv), s_res = wave_sum_u64(reseeds), s_cl = wave_sum_u64(clamps);
+    unsigned long long s_mx = wave_sum_u64(maxit), s_ov = wave_sum_u64(overflow);
+    int m_reach = wave_max_i32(reach);
+    if ((threadIdx.x & 63) == 0) {
+        if (s_rhs) atomicAdd(&A.cnt->rhs, s_rhs);
+        if (s_acc) atomicAdd(&A.cnt->acc, s_acc);
+        if (s_rej) atomicAdd(&A.cnt->rej, s_rej);
+        if (s_adv) atomicAdd(&A.cnt->adv, s_adv);
+        if (s_res) atomicAdd(&A.cnt->reseeds, s_res);
+        if (s_cl) atomicAdd(&A.cnt->clamps, s_cl);
+        if (s_mx) atomicAdd(&A.cnt->maxit, s_mx);
+        if (s_ov) atomicAdd(&A.cnt->overflow, s_ov);
+        if (m_reach) atomicMax(&A.cnt->max_reach, m_reach);
+    }
+}
+
+/* NodeToParticle! (mapping_2D.jl:279-356) on the node value (e,mx,my) held in registers */
+__device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &A, long long t, unsigned char pf,
+                                                double e, double mx, double my, double clock, double DT,
+                                                unsigned int &reseeds)
+{
+    Wind w = load_wind(P, A, t);
+    double u, v;
+    wind_at(P, w, clock, u, v);          /* winds at model.clock.time, before tick! */
+    bool bnd = (pf & PF_BOUNDARY) != 0;
+    Vec5 z;
+    if (!bnd && (e >= P.min_e) && (mx * mx + my * my >= P.min_m2)) {          /* A */
+        charge_to_particle(e, mx, my, z);
+        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
+        A.dtn[t] = -1.0;
+        A.on[t] = 1;
+    } else if (u * u + v * v >= P.wind_min_sq) {                               /* B, C */
+        reseed(P, u, v, DT, z);
+        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
+        A.qold[t] = PI_QOLDINIT;   /* reinit! */
+        A.dtn[t] = -1.0;
+        A.on[t] = 1;
+        reseeds = 1;
+    } else {                                                                    /* D */
+        A.on[t] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_scatter — ParticleToNode! / push_to_grid! (mapping_2D.jl:59-73, ParticleInCell.jl:341-376,
+ * 504-508,530-538) as a deterministic PULL: node (i,j) visits its (2R+1)² candidate source
+ * particles in the reference's sequential order (ocean list then grid-boundary list, each
+ * column-major; periodic wraps sorted by their wrapped index) and adds (wx*wy)*charge of the
+ * one corner that lands on it.  Drop/wrap per axis follows the GRID's periodicity.
+ * Fused: State zero-fill (accum=0), MovieState snapshot + post-remesh zero (movie=1),
+ * remesh (REMESH).
+ * ---------------------------------------------------------------------------------------- */
+template <bool REMESH>
+__global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, int accum, int movie,
+                                                   double clock, double DT)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int reseeds = 0;
+    if (t < A.n) {
+        int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
+        int j = jl + G.j_begin;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (accum) { s0 = A.state[t]; s1 = A.state[t + A.n]; s2 = A.state[t + 2 * A.n]; }
+        const int R = G.R, W = 2 * R + 1;
+        int shx = 0, shy = 0;
+        if (G.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= G.Nx) shx = G.Nx - i + R; }
+        if (G.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= G.Ny) shy = G.Ny - j + R; }
+        for (int grp = 1; grp <= G.ngroups; grp++) {
+            const double fgrp = (double)grp;
+            for (int sj = 0; sj < W; sj++) {
+                int qj = sj + shy; if (qj >= W) qj -= W;
+                int dj = qj - R;
+                int jj = j + dj;
+                if (!G.periodic_y && (jj < 0 || jj >= G.Ny)) continue;
+                int row;
+                if (G.single_slab) {
+                    int jw = jj; if (jw < 0) jw += G.Ny; else if (jw >= G.Ny) jw -= G.Ny;
+                    row = jw + R;
+                } else {
+                    row = jl + dj + R;
+                }
+                const double *rr = rec_row(A, G, row);
+                for (int si = 0; si < W; si++) {
+                    int qi = si + shx; if (qi >= W) qi -= W;
+                    int di = qi - R;
+                    int ii = i + di;
+                    if (ii < 0) { if (!G.periodic_x) continue; ii += G.Nx; }
+                    else if (ii >= G.Nx) { if (!G.periodic_x) continue; ii -= G.Nx; }
+                    if (rr[5 * G.Nx + ii] != fgrp) continue;
+                    double xs = rr[3 * G.Nx + ii], ys = rr[4 * G.Nx + ii];
+                    int bx, by;
+                    double wxh, wyh;
+                    index_weight(xs, bx, wxh);
+                    index_weight(ys, by, wyh);
+                    int ax = -di - bx, ay = -dj - by;
+                    if (ax < 0 || ax > 1 || ay < 0 || ay > 1) continue;
+                    double wx = ax ? wxh : 1.0 - wxh;
+                    double wy = ay ? wyh : 1.0 - wyh;
+                    double w = wx * wy;
+                    s0 += w * rr[ii];
+                    s1 += w * rr[G.Nx + ii];
+                    s2 += w * rr[2 * G.Nx + ii];
+                }
+            }
+        }
+        if (movie) {
+            A.movie[t] = s0; A.movie[t + A.n] = s1; A.movie[t + 2 * A.n] = s2;
+            A.state[t] = 0.0; A.state[t + A.n] = 0.0; A.state[t + 2 * A.n] = 0.0;
+        } else {
+            A.state[t] = s0; A.state[t + A.n] = s1; A.state[t + 2 * A.n] = s2;
+        }
+        if (REMESH) {
+            unsigned char pf = A.pflags[t];
+            if (pf & PF_STEPPED) remesh_particle(P, A, t, pf, s0, s1, s2, clock, DT, reseeds);
+        }
+    }
+    if (REMESH) {
+        unsigned long long s = wave_sum_u64(reseeds);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&A.cnt->reseeds, s);
+    }
+}
+
+/* stand-alone time_step!_remesh (TimeSteppers.jl:182-193) */
+__global__ void __launch_bounds__(256) k_remesh(KParams P, GridP G, Arrays A, double clock, double DT)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int reseeds = 0;
+    if (t < A.n) {
+        unsigned char pf = A.pflags[t];
+        if (pf & PF_STEPPED)
+            remesh_particle(P, A, t, pf, A.state[t], A.state[t + A.n], A.state[t + 2 * A.n], clock, DT, reseeds);
+    }
+    unsigned long long s = wave_sum_u64(reseeds);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&A.cnt->reseeds, s);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_push_tiles — PUSH scatter with an LDS-staged grid tile.
+ * One workgroup owns a TX×TY tile of birth nodes; its LDS holds the tile plus an apron of AP
+ * nodes on every side (3 planes).  Every on-particle of the tile adds its 4 weighted corners
+ * with ds_add_f64 (LDS atomics resolve same-node collisions inside the workgroup); corners
+ * beyond the apron go straight to global fp64 atomics.  The LDS tile is then flushed with ONE
+ * global atomic per touched node (drop / wrap by the grid's periodicity).
+ * Sum order is not fixed => last-bit run-to-run differences; PICLES_STEP_ATOMIC selects it.
+ * IDENTITY=true : particles = the tile's own nodes, read from the scatter records.
+ * IDENTITY=false: particles = a cell-list segment of an arbitrary particle list
+ *                 (picles_scatter_particles), sorted by the tile of the birth node.
+ * ---------------------------------------------------------------------------------------- */
+#define PT_TX 64
+#define PT_TY 4
+#define PT_AP 2
+#define PT_LX (PT_TX + 2 * PT_AP)
+#define PT_LY (PT_TY + 2 * PT_AP)
+
+__device__ __forceinline__ void global_add3(const GridP &G, const Arrays &A, int ig, int jg, double a0, double a1, double a2)
+{
+    /* ig, jg: unwrapped global node indices */
+    if (ig < 0 || ig >= G.Nx) { if (!G.periodic_x) return; ig %= G.Nx; if (ig < 0) ig += G.Nx; }
+    if (jg < 0 || jg >= G.Ny) { if (!G.periodic_y) return; jg %= G.Ny; if (jg < 0) jg += G.Ny; }
+    int jl = jg - G.j_begin;
+    if (jl < 0 || jl >= G.ny_loc) return;   /* other slab: single-slab use only */
+    long long t = (long long)jl * G.Nx + ig;
+    unsafeAtomicAdd(&A.state[t], a0);
+    unsafeAtomicAdd(&A.state[t + A.n], a1);
+    unsafeAtomicAdd(&A.state[t + 2 * A.n], a2);
+}
+
+template <bool IDENTITY>
+__global__ void __launch_bounds__(256) k_push_tiles(GridP G, Arrays A, int ntx,
+                                                      const int *seg_start, const int *perm,
+                                                      const int *pij, const double *pxy, const double *pch, long long np)
+{
+    __shared__ double tile[3][PT_LY][PT_LX];
+    const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+    const int i0 = tx * PT_TX, j0 = ty * PT_TY + G.j_begin;   /* global origin of the tile */
+    for (int k = threadIdx.x; k < 3 * PT_LY * PT_LX; k += blockDim.x) (&tile[0][0][0])[k] = 0.0;
+    __syncthreads();
+
+    int count, base = 0;
+    if (IDENTITY) count = PT_TX * PT_TY;
+    else { base = seg_start[blockIdx.x]; count = seg_start[blockIdx.x + 1] - base; }
+    for (int k = threadIdx.x; k < count; k += blockDim.x) {
+        int ib, jb;          /* birth node, global */
+        double x, y, e, mx, my;
+        if (IDENTITY) {
+            ib = i0 + (k % PT_TX);
+            jb = j0 + (k / PT_TX);
+            int jl = jb - G.j_begin;
+            if (ib >= G.Nx || jl >= G.ny_loc) continue;
+            const double *rr = rec_row(A, G, jl + G.R);
+            if (rr[5 * G.Nx + ib] == 0.0) continue;
+            e = rr[ib]; mx = rr[G.Nx + ib]; my = rr[2 * G.Nx + ib]; x = rr[3 * G.Nx + ib]; y = rr[4 * G.Nx + ib];
+        } else {
+            long long pidx = perm[base + k];
+            ib = pij[pidx]; jb = pij[np + pidx];
+            x = pxy[pidx]; y = pxy[np + pidx];
+            e = pch[pidx]; mx = pch[np + pidx]; my = pch[2 * np + pidx];
+            if (!(pm_isfinite(x) && pm_isfinite(y))) continue;
+        }
+        int bx, by;
+        double wxh, wyh;
+        index_weight(x, bx, wxh);
+        index_weight(y, by, wyh);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int ax = c & 1, ay = c >> 1;
+            int ig = ib + bx + ax, jg = jb + by + ay;
+            double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
+            int li = ig - i0 + PT_AP, lj = jg - j0 + PT_AP;
+            if (li >= 0 && li < PT_LX && lj >= 0 && lj < PT_LY) {
+                atomicAdd(&tile[0][lj][li], w * e);
+                atomicAdd(&tile[1][lj][li], w * mx);
+                atomicAdd(&tile[2][lj][li], w * my);
+            } else {
+                global_add3(G, A, ig, jg, w * e, w * mx, w * my);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < PT_LY * PT_LX; k += blockDim.x) {
+        int li = k % PT_LX, lj = k / PT_LX;
+        double a0 = tile[0][lj][li], a1 = tile[1][lj][li], a2 = tile[2][lj][li];
+        if (a0 == 0.0 && a1 == 0.0 && a2 == 0.0) continue;
+        global_add3(G, A, i0 + li - PT_AP, j0 + lj - PT_AP, a0, a1, a2);
+    }
+}
+
+/* cell list for an arbitrary particle list: histogram of birth tiles, then (after an exclusive
+ * scan) a stable-enough fill of the permutation */
+__global__ void k_tile_count(GridP G, int ntx, const int *pij, long long np, int *count, int *tile_of)
+{
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= np) return;
+    int ib = pij[k], jb = pij[np + k] - G.j_begin;
+    int tile = -1;
+    if (ib >= 0 && ib < G.Nx && jb >= 0 && jb < G.ny_loc) {
+        tile = (jb / PT_TY) * ntx + ib / PT_TX;
+        atomicAdd(&count[tile], 1);
+    }
+    tile_of[k] = tile;
+}
+__global__ void k_tile_fill(long long np, const int *tile_of, const int *seg_start, int *cursor, int *perm)
+{
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= np) return;
+    int tile = tile_of[k];
+    if (tile < 0) return;
+    int pos = atomicAdd(&cursor[tile], 1);
+    perm[seg_start[tile] + pos] = (int)k;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * host side
+ * ---------------------------------------------------------------------------------------- */
+static thread_local std::string g_create_error;
+
+struct picles_ctx {
+    picles_grid g;
+    picles_phys ph;
+    picles_ode od;
+    picles_model md;
+    KParams P;
+    GridP G;
+    Arrays A;
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev_edge;
+    bool edge_pending = false;
+    signed char *d_mask = nullptr;
+    std::vector<signed char> h_mask;
+    double clock = 0.0;
+    /* pending step (begin_step .. scatter_remesh) */
+    double step_dt = 0.0;
+    int step_flags = 0;
+    bool state_zero = false;      /* State known to be all zero (skip the accumulate read) */
+    bool seeded = false;
+    /* timing */
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int kind; };
+    std::vector<Ev> ev_used, ev_free;
+    picles_timing tim{};
+    std::string err;
+    /* generic scatter scratch */
+    int *d_count = nullptr, *d_start = nullptr, *d_cursor = nullptr;
+    void *d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return -10;                                                                        \
+        }                                                                                      \
+    } while (0)
+
+static int fail(picles_ctx *c, int code, const std::string &m)
+{
+    c->err = m;
+    return code;
+}
+
+static void timing_begin(picles_ctx *c, hipStream_t s, int kind)
+{
+    if (!c->timing) return;
+    picles_ctx::Ev e;
+    if (!c->ev_free.empty()) { e = c->ev_free.back(); c->ev_free.pop_back(); }
+    else { hipEventCreate(&e.a); hipEventCreate(&e.b); }
+    e.kind = kind;
+    hipEventRecord(e.a, s);
+    c->ev_used.push_back(e);
+}
+static void timing_end(picles_ctx *c, hipStream_t s)
+{
+    if (!c->timing) return;
+    hipEventRecord(c->ev_used.back().b, s);
+}
+static void timing_collect(picles_ctx *c)
+{
+    for (auto &e : c->ev_used) {
+        hipEventSynchronize(e.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e.a, e.b);
+        switch (e.kind) {
+        case 0: c->tim.advance_ms += ms; c->tim.advance_launches++; break;
+        case 1: c->tim.scatter_ms += ms; c->tim.scatter_launches++; break;
+        case 2: c->tim.remesh_ms += ms; c->tim.remesh_launches++; break;
+        default: c->tim.other_ms += ms;
+        }
+        c->ev_free.push_back(e);
+    }
+    c->ev_used.clear();
+}
+
+static size_t rec_bytes(const picles_ctx *c) { return (size_t)(c->G.ny_loc + 2 * c->G.R) * 6 * c->G.Nx * sizeof(double); }
+
+static int alloc_rec(picles_ctx *c)
+{
+    if (c->A.rec) HIPCHK(c, hipFree(c->A.rec));
+    c->A.rec = nullptr;
+    HIPCHK(c, hipMalloc(&c->A.rec, rec_bytes(c)));
+    HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
+    return 0;
+}
+
+PX_EXPORT int32_t picles_abi_version(void) { return PICLES_ABI_VERSION; }
+
+PX_EXPORT const char *picles_last_error(const picles_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, const picles_ode *o,
+                                const picles_model *m, int32_t device_id, int32_t halo_rows, picles_ctx **out)
+{
+    if (!g || !p || !o || !m || !out) { g_create_error = "null argument"; return -1; }
+    *out = nullptr;
+    if (g->Nx < 2 || g->Ny < 2) { g_create_error = "grid must be at least 2x2"; return -2; }
+    if (g->j_begin < 0 || g->j_end > g->Ny || g->j_end <= g->j_begin) { g_create_error = "bad slab rows [j_begin,j_end)"; return -2; }
+    if (o->solver != 0) { g_create_error = "only solver 0 (DP5) is implemented"; return -3; }
+    if (halo_rows < 1) halo_rows = 1;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device available (this library has no CPU path)";
+        return -4;
+    }
+    if (device_id < 0 || device_id >= ndev) { g_create_error = "device_id out of range"; return -4; }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = hipGetErrorString(e); return -4; }
+
+    picles_ctx *c = new picles_ctx();
+    c->g = *g; c->ph = *p; c->od = *o; c->md = *m;
+    c->device = device_id;
+    /* derived constants: magic_fractions :87-92, e_T_func :271 (same primitives as the kernels) */
+    KParams &P = c->P;
+    P.r_g = p->r_g; P.inv_rg = 1.0 / p->r_g; P.C_alpha = p->C_alpha; P.C_phi = p->C_phi; P.C_e = p->C_e;
+    double q = p->q;
+    P.p = (-1.0 - 10.0 * q) / 2.0;
+    P.n = 2.0 * q / (P.p + 4.0 * q);
+    P.neg2p = -2.0 * P.p;
+    double e_T = std::sqrt(p->c_e * pm_pow(p->c_alpha, -P.p / q) / pm_pow(p->gamma * p->c_beta * p->c_D, 1.0 / P.n));
+    P.inv_eT = 1.0 / e_T;
+    P.inv_dx = 1.0 / g->dx; P.inv_dy = 1.0 / g->dy;
+    P.propagation = p->propagation; P.input = p->input; P.dissipation = p->dissipation;
+    P.peak_shift = p->peak_shift; P.direction = p->direction; P.n_is_2 = (P.n == 2.0);
+    P.abstol = o->abstol; P.reltol = o->reltol; P.dt0 = o->dt0; P.dtmin = o->dtmin;
+    P.maxiters = o->maxiters; P.force_dtmin = o->force_dtmin;
+    P.lne_max = o->log_energy_maximum; P.wind_min_sq = o->wind_min_squared;
+    P.init_type = m->init_type;
+    P.def_lne = m->default_particle[0]; P.def_cx = m->default_particle[1]; P.def_cy = m->default_particle[2];
+    P.min_e = m->minimal_state[0]; P.min_m2 = m->minimal_state[1];
+    P.wind_static = 1; P.tw0 = 0.0; P.inv_dtw = 0.0;
+
+    GridP &G = c->G;
+    G.Nx = g->Nx; G.Ny = g->Ny; G.periodic_x = g->periodic_x; G.periodic_y = g->periodic_y;
+    G.j_begin = g->j_begin; G.ny_loc = g->j_end - g->j_begin;
+    G.single_slab = (g->j_begin == 0 && g->j_end == g->Ny);
+    G.R = halo_rows;
+    G.ngroups = 1;
+
+    /* total mask (mask_utils.jl:38-55) for the local rows */
+    long long n = (long long)G.Nx * G.ny_loc;
+    c->h_mask.resize(n);
+    for (int jl = 0; jl < G.ny_loc; jl++)
+        for (int i = 0; i < G.Nx; i++) {
+            int j = jl + G.j_begin;
+            signed char mk;
+            if (g->mask) mk = g->mask[(long long)j * G.Nx + i];
+            else {
+                bool ring = (!g->periodic_x && (i == 0 || i == G.Nx - 1)) || (!g->periodic_y && (j == 0 || j == G.Ny - 1));
+                mk = ring ? 3 : 1;
+            }
+            c->h_mask[(long long)jl * G.Nx + i] = mk;
+        }
+    /* ocean_points (WaveGrowthModels2D.jl:256-270) and check_boundary_point (core_2D.jl:360-366) */
+    std::vector<unsigned char> pf(n, 0);
+    bool any3 = false;
+    if (g->mask) { for (long long k = 0; k < (long long)G.Nx * G.Ny; k++) if (g->mask[k] == 3) { any3 = true; break; } }
+    else any3 = (!g->periodic_x || !g->periodic_y);
+    for (long long k = 0; k < n; k++) {
+        signed char mk = c->h_mask[k];
+        unsigned char f = 0;
+        if (mk == 1) f |= PF_STEPPED;
+        if (mk == 3 && m->periodic_boundary) f |= PF_STEPPED | PF_GROUP2;
+        bool bnd = m->periodic_boundary ? (mk == 2) : (mk >= 2);
+        if (bnd) f |= PF_BOUNDARY;
+        pf[k] = f;
+    }
+    if (any3 && m->periodic_boundary) G.ngroups = 2;
+    if (G.single_slab) {
+        if ((G.periodic_x && G.Nx <= 2 * G.R) || (G.periodic_y && G.Ny <= 2 * G.R)) {
+            g_create_error = "periodic axis shorter than 2*halo_rows+1";
+            delete c;
+            return -2;
+        }
+    }
+
+#define CK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e2); delete c; return -10; } } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
+    Arrays &A = c->A;
+    memset(&A, 0, sizeof(A));
+    A.n = n;
+    CK(hipMalloc(&A.state, 3 * n * 8)); CK(hipMalloc(&A.movie, 3 * n * 8));
+    CK(hipMalloc(&A.z, 5 * n * 8));
+    CK(hipMalloc(&A.qold, n * 8)); CK(hipMalloc(&A.dtn, n * 8));
+    CK(hipMalloc(&A.on, n)); CK(hipMalloc(&A.pflags, n)); CK(hipMalloc(&A.status, n * 4));
+    CK(hipMalloc(&A.u0, n * 8)); CK(hipMalloc(&A.v0, n * 8)); CK(hipMalloc(&A.u1, n * 8)); CK(hipMalloc(&A.v1, n * 8));
+    CK(hipMalloc(&A.cnt, sizeof(DevCounters)));
+    CK(hipMalloc(&c->d_mask, n));
+    CK(hipMemset(A.state, 0, 3 * n * 8)); CK(hipMemset(A.movie, 0, 3 * n * 8)); CK(hipMemset(A.z, 0, 5 * n * 8));
+    CK(hipMemset(A.qold, 0, n * 8)); CK(hipMemset(A.dtn, 0, n * 8)); CK(hipMemset(A.on, 0, n)); CK(hipMemset(A.status, 0, n * 4));
+    CK(hipMemset(A.u0, 0, n * 8)); CK(hipMemset(A.v0, 0, n * 8)); CK(hipMemset(A.u1, 0, n * 8)); CK(hipMemset(A.v1, 0, n * 8));
+    CK(hipMemset(A.cnt, 0, sizeof(DevCounters)));
+    CK(hipMemcpy(A.pflags, pf.data(), n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_mask, c->h_mask.data(), n, hipMemcpyHostToDevice));
+    CK(hipMalloc(&A.rec, rec_bytes(c)));
+    CK(hipMemset(A.rec, 0, rec_bytes(c)));
+#undef CK
+    c->state_zero = true;
+    *out = c;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_destroy(picles_ctx *c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    Arrays &A = c->A;
+    hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
+    hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
+    hipFree(A.cnt); hipFree(A.rec); hipFree(c->d_mask);
+    if (c->d_count) hipFree(c->d_count);
+    if (c->d_start) hipFree(c->d_start);
+    if (c->d_cursor) hipFree(c->d_cursor);
+    if (c->d_scan_tmp) hipFree(c->d_scan_tmp);
+    for (auto &e : c->ev_used) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto &e : c->ev_free) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    hipEventDestroy(c->ev_edge);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_sync(picles_ctx *c)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+PX_EXPORT double picles_clock(const picles_ctx *c) { return c ? c->clock : 0.0; }
+
+PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double *v0, double t0,
+                                   const double *u1, const double *v1, double t1)
+{
+    if (!c || !u0 || !v0) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t b = (size_t)c->A.n * 8;
+    HIPCHK(c, hipMemcpyAsync(c->A.u0, u0, b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->A.v0, v0, b, hipMemcpyHostToDevice, c->stream));
+    if (u1 && v1 && t1 != t0) {
+        HIPCHK(c, hipMemcpyAsync(c->A.u1, u1, b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->A.v1, v1, b, hipMemcpyHostToDevice, c->stream));
+        c->P.wind_static = 0;
+        c->P.tw0 = t0;
+        c->P.inv_dtw = 1.0 / (t1 - t0);
+    } else {
+        c->P.wind_static = 1;
+        c->P.tw0 = t0;
+        c->P.inv_dtw = 0.0;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));   /* caller may reuse its host buffers */
+    return 0;
+}
+
+static inline unsigned nblocks(long long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->clock = t0;
+    HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, sizeof(DevCounters), c->stream));
+    hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, c->A, c->d_mask, c->od.timestep);
+    HIPCHK(c, hipGetLastError());
+    c->state_zero = false;
+    c->seeded = true;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_zero_state(picles_ctx *c)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->A.state, 0, 3 * c->A.n * 8, c->stream));
+    c->state_zero = true;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_tick(picles_ctx *c, double dt)
+{
+    if (!c) return -1;
+    c->clock += dt;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
+{
+    if (!c) return -1;
+    if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
+    c->step_dt = dt;
+    c->step_flags = flags;
+    c->edge_pending = false;
+    HIPCHK(c, hipSetDevice(c->device));
+    /* max_reach / overflow are per-advance quantities */
+    HIPCHK(c, hipMemsetAsync(&c->A.cnt->max_reach, 0, sizeof(int), c->stream));
+    return 0;
+}
+
+PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const GridP &G = c->G;
+    int R = G.R;
+    int r0 = 0, n0 = 0, r1 = 0, n1 = 0;
+    bool small = G.ny_loc <= 2 * R;
+    if (which == PICLES_ROWS_ALL) { r0 = 0; n0 = G.ny_loc; }
+    else if (which == PICLES_ROWS_EDGE) {
+        if (small) { r0 = 0; n0 = G.ny_loc; }
+        else { r0 = 0; n0 = R; r1 = G.ny_loc - R; n1 = R; }
+    } else if (which == PICLES_ROWS_INTERIOR) {
+        if (small) return 0;
+        r0 = R; n0 = G.ny_loc - 2 * R;
+    } else return fail(c, -2, "bad row selector");
+    long long nt = (long long)(n0 + n1) * G.Nx;
+    if (nt == 0) return 0;
+    timing_begin(c, s, 0);
+    hipLaunchKernelGGL(k_advance, dim3(nblocks(nt, 256)), dim3(256), 0, s, c->P, c->G, c->A, c->clock, c->step_dt, r0, n0, r1, n1);
+    timing_end(c, s);
+    HIPCHK(c, hipGetLastError());
+    if (which == PICLES_ROWS_EDGE && s != c->stream) {
+        HIPCHK(c, hipEventRecord(c->ev_edge, s));
+        c->edge_pending = true;
+    }
+    return 0;
+}
+
+static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh)
+{
+    int flags = c->step_flags;
+    bool movie = (flags & PICLES_STEP_MOVIE) != 0;
+    bool zero_first = (flags & PICLES_STEP_ZERO_FIRST) != 0;
+    int accum = (zero_first || c->state_zero) ? 0 : 1;
+    if (flags & PICLES_STEP_ATOMIC) {
+        if (!c->G.single_slab) return fail(c, -5, "PICLES_STEP_ATOMIC is single-slab only");
+        if (!accum) HIPCHK(c, hipMemsetAsync(c->A.state, 0, 3 * c->A.n * 8, s));
+        int ntx = (c->G.Nx + PT_TX - 1) / PT_TX, nty = (c->G.ny_loc + PT_TY - 1) / PT_TY;
+        timing_begin(c, s, 1);
+        hipLaunchKernelGGL(k_push_tiles<true>, dim3(ntx * nty), dim3(256), 0, s, c->G, c->A, ntx,
+                           (const int *)nullptr, (const int *)nullptr, (const int *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr, 0LL);
+        timing_end(c, s);
+        HIPCHK(c, hipGetLastError());
+        if (movie) HIPCHK(c, hipMemcpyAsync(c->A.movie, c->A.state, 3 * c->A.n * 8, hipMemcpyDeviceToDevice, s));
+        if (remesh) {
+            timing_begin(c, s, 2);
+            hipLaunchKernelGGL(k_remesh, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, c->A, c->clock, c->step_dt);
+            timing_end(c, s);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (movie && remesh) HIPCHK(c, hipMemsetAsync(c->A.state, 0, 3 * c->A.n * 8, s));
+        c->state_zero = movie && remesh;
+        return 0;
+    }
+    timing_begin(c, s, 1);
+    if (remesh)
+        hipLaunchKernelGGL(k_scatter<true>, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, c->A, accum, movie ? 1 : 0, c->clock, c->step_dt);
+    else
+        hipLaunchKernelGGL(k_scatter<false>, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, c->A, accum, 0, c->clock, c->step_dt);
+    timing_end(c, s);
+    HIPCHK(c, hipGetLastError());
+    c->state_zero = movie && remesh;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_scatter_remesh(picles_ctx *c, void *stream)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (c->edge_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_edge, 0)); c->edge_pending = false; }
+    int rc = launch_scatter(c, s, true);
+    if (rc) return rc;
+    c->clock += c->step_dt;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_time_step(picles_ctx *c, double dt, int32_t flags)
+{
+    if (!c) return -1;
+    if (!c->G.single_slab) return fail(c, -5, "picles_time_step needs the whole grid; slabs use begin_step/advance_rows/scatter_remesh");
+    int rc = picles_begin_step(c, dt, flags);
+    if (rc) return rc;
+    rc = picles_advance_rows(c, PICLES_ROWS_ALL, nullptr);
+    if (rc) return rc;
+    return picles_scatter_remesh(c, nullptr);
+}
+
+PX_EXPORT int32_t picles_advance(picles_ctx *c, double dt, int32_t flags)
+{
+    if (!c) return -1;
+    if (!c->G.single_slab) return fail(c, -5, "picles_advance needs the whole grid");
+    int rc = picles_begin_step(c, dt, flags & ~(PICLES_STEP_MOVIE));
+    if (rc) return rc;
+    rc = picles_advance_rows(c, PICLES_ROWS_ALL, nullptr);
+    if (rc) return rc;
+    return launch_scatter(c, c->stream, false);
+}
+
+PX_EXPORT int32_t picles_remesh(picles_ctx *c, double dt)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_begin(c, c->stream, 2);
+    hipLaunchKernelGGL(k_remesh, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, c->A, c->clock, dt);
+    timing_end(c, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+/* ---- data access ---- */
+static int d2h(picles_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int h2d(picles_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+PX_EXPORT int32_t picles_get_state(picles_ctx *c, double *s) { return (c && s) ? d2h(c, s, c->A.state, 3 * c->A.n * 8) : -1; }
+PX_EXPORT int32_t picles_get_movie_state(picles_ctx *c, double *s) { return (c && s) ? d2h(c, s, c->A.movie, 3 * c->A.n * 8) : -1; }
+PX_EXPORT int32_t picles_set_state(picles_ctx *c, const double *s)
+{
+    if (!c || !s) return -1;
+    c->state_zero = false;
+    return h2d(c, c->A.state, s, 3 * c->A.n * 8);
+}
+
+PX_EXPORT int32_t picles_get_particles(picles_ctx *c, double *z, uint8_t *on, uint8_t *boundary, int32_t *status)
+{
+    if (!c) return -1;
+    int rc = 0;
+    if (z && (rc = d2h(c, z, c->A.z, 5 * c->A.n * 8))) return rc;
+    if (on && (rc = d2h(c, on, c->A.on, c->A.n))) return rc;
+    if (status && (rc = d2h(c, status, c->A.status, c->A.n * 4))) return rc;
+    if (boundary) {
+        std::vector<unsigned char> pf(c->A.n);
+        if ((rc = d2h(c, pf.data(), c->A.pflags, c->A.n))) return rc;
+        for (long long k = 0; k < c->A.n; k++) boundary[k] = (pf[k] & PF_BOUNDARY) ? 1 : 0;
+    }
+    return 0;
+}
+
+PX_EXPORT int32_t picles_set_particles(picles_ctx *c, const double *z, const uint8_t *on)
+{
+    if (!c) return -1;
+    int rc = 0;
+    if (z && (rc = h2d(c, c->A.z, z, 5 * c->A.n * 8))) return rc;
+    if (on && (rc = h2d(c, c->A.on, on, c->A.n))) return rc;
+    std::vector<double> neg(c->A.n, -1.0);   /* auto_dt_reset! on the next advance */
+    return h2d(c, c->A.dtn, neg.data(), c->A.n * 8);
+}
+
+PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
+{
+    if (!c || !out) return -1;
+    DevCounters d;
+    int rc = d2h(c, &d, c->A.cnt, sizeof(d));
+    if (rc) return rc;
+    out->rhs_evals = d.rhs; out->steps_accepted = d.acc; out->steps_rejected = d.rej;
+    out->reseeds = d.reseeds; out->clamps = d.clamps; out->maxiters_hits = d.maxit;
+    out->particles_advanced = d.adv; out->halo_overflow = d.overflow; out->max_reach = d.max_reach; out->_pad = 0;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, sizeof(DevCounters), c->stream));
+    return 0;
+}
+
+PX_EXPORT int32_t picles_enable_timing(picles_ctx *c, int32_t on)
+{
+    if (!c) return -1;
+    timing_collect(c);
+    c->timing = on != 0;
+    if (on) memset(&c->tim, 0, sizeof(c->tim));
+    return 0;
+}
+
+PX_EXPORT int32_t picles_get_timing(picles_ctx *c, picles_timing *t)
+{
+    if (!c || !t) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    timing_collect(c);
+    *t = c->tim;
+    return 0;
+}
+
+/* ---- halo blocks ---- */
+PX_EXPORT int32_t picles_halo_rows(const picles_ctx *c) { return c ? c->G.R : -1; }
+
+PX_EXPORT int32_t picles_set_halo_rows(picles_ctx *c, int32_t r)
+{
+    if (!c || r < 1) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->G.single_slab && ((c->G.periodic_x && c->G.Nx <= 2 * r) || (c->G.periodic_y && c->G.Ny <= 2 * r)))
+        return fail(c, -2, "periodic axis shorter than 2*halo_rows+1");
+    /* keep the records of the own rows: re-pack into the new ghost-row geometry */
+    int oldR = c->G.R;
+    size_t row_b = (size_t)6 * c->G.Nx * 8;
+    double *old = c->A.rec;
+    c->A.rec = nullptr;
+    c->G.R = r;
+    HIPCHK(c, hipMalloc(&c->A.rec, rec_bytes(c)));
+    HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
+    HIPCHK(c, hipMemcpyAsync((char *)c->A.rec + (size_t)r * row_b, (char *)old + (size_t)oldR * row_b,
+                             (size_t)c->G.ny_loc * row_b, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(old));
+    return 0;
+}
+
+static int halo_ptr(picles_ctx *c, int side, bool send, void **ptr, size_t *bytes)
+{
+    if (!c || !ptr || !bytes || side < 0 || side > 1) return -1;
+    const GridP &G = c->G;
+    if (G.ny_loc < G.R) return fail(c, -2, "slab has fewer rows than halo_rows");
+    size_t row_b = (size_t)6 * G.Nx * 8;
+    int row;
+    if (send) row = (side == 0) ? G.R : G.ny_loc;          /* own first R rows / own last R rows */
+    else row = (side == 0) ? 0 : G.ny_loc + G.R;            /* ghost rows below / above */
+    *ptr = (char *)c->A.rec + (size_t)row * row_b;
+    *bytes = (size_t)G.R * row_b;
+    return 0;
+}
+PX_EXPORT int32_t picles_halo_send_dev(picles_ctx *c, int32_t side, void **ptr, size_t *bytes) { return halo_ptr(c, side, true, ptr, bytes); }
+PX_EXPORT int32_t picles_halo_recv_dev(picles_ctx *c, int32_t side, void **ptr, size_t *bytes) { return halo_ptr(c, side, false, ptr, bytes); }
+
+/* ---- generic push_to_grid! of a particle list ---- */
+PX_EXPORT int32_t picles_scatter_particles(picles_ctx *c, int64_t np, const int32_t *ij, const double *xy, const double *charge)
+{
+    if (!c || np < 0 || (np > 0 && (!ij || !xy || !charge))) return -1;
+    if (!c->G.single_slab) return fail(c, -5, "picles_scatter_particles is single-slab only");
+    if (np == 0) return 0;
+    if (np > 0x7fffffffLL) return fail(c, -2, "too many particles for one call");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int ntx = (c->G.Nx + PT_TX - 1) / PT_TX, nty = (c->G.ny_loc + PT_TY - 1) / PT_TY;
+    int ntiles = ntx * nty;
+    int *d_ij = nullptr, *d_tile = nullptr, *d_perm = nullptr;
+    double *d_xy = nullptr, *d_ch = nullptr;
+    HIPCHK(c, hipMalloc(&d_ij, 2 * np * 4)); HIPCHK(c, hipMalloc(&d_tile, np * 4)); HIPCHK(c, hipMalloc(&d_perm, np * 4));
+    HIPCHK(c, hipMalloc(&d_xy, 2 * np * 8)); HIPCHK(c, hipMalloc(&d_ch, 3 * np * 8));
+    if (!c->d_count) {
+        HIPCHK(c, hipMalloc(&c->d_count, (ntiles + 1) * 4));
+        HIPCHK(c, hipMalloc(&c->d_start, (ntiles + 1) * 4));
+        HIPCHK(c, hipMalloc(&c->d_cursor, (ntiles + 1) * 4));
+        hipcub::DeviceScan::ExclusiveSum(nullptr, c->scan_tmp_bytes, c->d_count, c->d_start, ntiles + 1, s);
+        HIPCHK(c, hipMalloc(&c->d_scan_tmp, c->scan_tmp_bytes));
+    }
+    HIPCHK(c, hipMemcpyAsync(d_ij, ij, 2 * np * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_xy, xy, 2 * np * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_ch, charge, 3 * np * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->d_count, 0, (ntiles + 1) * 4, s));
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, (ntiles + 1) * 4, s));
+    hipLaunchKernelGGL(k_tile_count, dim3(nblocks(np, 256)), dim3(256), 0, s, c->G, ntx, d_ij, (long long)np, c->d_count, d_tile);
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->d_scan_tmp, c->scan_tmp_bytes, c->d_count, c->d_start, ntiles + 1, s));
+    hipLaunchKernelGGL(k_tile_fill, dim3(nblocks(np, 256)), dim3(256), 0, s, (long long)np, d_tile, c->d_start, c->d_cursor, d_perm);
+    timing_begin(c, s, 1);
+    hipLaunchKernelGGL(k_push_tiles<false>, dim3(ntiles), dim3(256), 0, s, c->G, c->A, ntx, c->d_start, d_perm, d_ij, d_xy, d_ch, (long long)np);
+    timing_end(c, s);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    hipFree(d_ij); hipFree(d_tile); hipFree(d_perm); hipFree(d_xy); hipFree(d_ch);
+    c->state_zero = false;
+    return 0;
+}

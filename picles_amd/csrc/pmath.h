@@ -1,0 +1,154 @@
+/*
+ * pmath.h — deterministic fp64 elementary functions shared by host and device.
+ *
+ * Why: the per-particle ODE advance is adaptive (accept/reject, PI step-size control) and,
+ * with C_phi = 0.04, numerically stiff — a 1-ulp difference between glibc's and the device
+ * library's exp/log/tanh is amplified to tolerance level.  To make "GPU == CPU oracle"
+ * a BITWISE statement, every transcendental on the path is built here from IEEE-754
+ * correctly rounded primitives only (+ - * / sqrt fma rint, bit moves), with every fused
+ * multiply-add written explicitly (translation units are compiled with -ffp-contract=off),
+ * so gcc on x86-64 and hipcc on gfx950 produce identical bits.
+ *
+ * Accuracy (measured in tests/test_pmath.py against glibc): exp, log < 1 ulp;
+ * pow(x,y) = exp(y log x) carries |y ln x| ulp (seeding only, compared at 1e-13).
+ *
+ * No reference counterpart: the reference calls Julia's libm-equivalents
+ * (particle_waves_v5.jl:274-275,331-340; FetchRelations.jl:128-203).
+ */
+#ifndef PICLES_PMATH_H
+#define PICLES_PMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PM_HD __host__ __device__ __forceinline__
+#else
+#define PM_HD static inline
+#endif
+
+#define PM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+PM_HD uint64_t pm_bits(double x)
+{
+    uint64_t u;
+    __builtin_memcpy(&u, &x, 8);
+    return u;
+}
+PM_HD double pm_from_bits(uint64_t u)
+{
+    double x;
+    __builtin_memcpy(&x, &u, 8);
+    return x;
+}
+PM_HD double pm_inf(void) { return pm_from_bits(0x7ff0000000000000ULL); }
+PM_HD double pm_nan(void) { return pm_from_bits(0x7ff8000000000000ULL); }
+PM_HD int pm_isnan(double x) { return x != x; }
+PM_HD int pm_isinf(double x) { return (pm_bits(x) & 0x7fffffffffffffffULL) == 0x7ff0000000000000ULL; }
+PM_HD int pm_isfinite(double x) { return (pm_bits(x) & 0x7ff0000000000000ULL) != 0x7ff0000000000000ULL; }
+PM_HD double pm_fabs(double x) { return pm_from_bits(pm_bits(x) & 0x7fffffffffffffffULL); }
+PM_HD double pm_max(double a, double b) { return (a > b) ? a : b; }   /* not NaN-propagating on b */
+PM_HD double pm_min(double a, double b) { return (a < b) ? a : b; }
+
+/* 2^k for -1022 <= k <= 1023 */
+PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
+
+/* exp(x): k = rint(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor/Horner, 2^k in two halves */
+PM_HD double pm_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.782712893384) return pm_inf();
+    if (x < -745.1332191019412) return 0.0;
+    const double L2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double k = __builtin_rint(x * L2E);
+    double r = PM_FMA(-k, LN2_HI, x);
+    r = PM_FMA(-k, LN2_LO, r);
+    double p = 1.6059043836821613e-10;            /* 1/13! */
+    p = PM_FMA(p, r, 2.08767569878681e-09);       /* 1/12! */
+    p = PM_FMA(p, r, 2.505210838544172e-08);      /* 1/11! */
+    p = PM_FMA(p, r, 2.755731922398589e-07);      /* 1/10! */
+    p = PM_FMA(p, r, 2.7557319223985893e-06);     /* 1/9!  */
+    p = PM_FMA(p, r, 2.48015873015873e-05);       /* 1/8!  */
+    p = PM_FMA(p, r, 1.984126984126984e-04);      /* 1/7!  */
+    p = PM_FMA(p, r, 1.388888888888889e-03);      /* 1/6!  */
+    p = PM_FMA(p, r, 8.333333333333333e-03);      /* 1/5!  */
+    p = PM_FMA(p, r, 4.1666666666666664e-02);     /* 1/4!  */
+    p = PM_FMA(p, r, 1.6666666666666666e-01);     /* 1/3!  */
+    p = PM_FMA(p, r, 0.5);
+    p = PM_FMA(p, r, 1.0);
+    p = PM_FMA(p, r, 1.0);
+    int ki = (int)k;
+    int k1 = ki / 2;
+    int k2 = ki - k1;
+    return (p * pm_pow2i(k1)) * pm_pow2i(k2);
+}
+
+/* log(x): fdlibm-style  x = 2^k (1+f), s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)) */
+PM_HD double pm_log(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0.0) return pm_nan();
+    if (x == 0.0) return -pm_inf();
+    if (pm_isinf(x)) return x;
+    int k = 0;
+    uint64_t ux = pm_bits(x);
+    if ((ux >> 52) == 0) { /* subnormal: scale by 2^54 */
+        x = x * 18014398509481984.0;
+        ux = pm_bits(x);
+        k = -54;
+    }
+    /* normalise mantissa into [sqrt(2)/2, sqrt(2)) */
+    uint32_t hx = (uint32_t)(ux >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    ux = ((uint64_t)hx << 32) | (ux & 0xffffffffULL);
+    double m = pm_from_bits(ux);
+    double f = m - 1.0;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * PM_FMA(w, PM_FMA(w, Lg6, Lg4), Lg2);
+    double t2 = z * PM_FMA(w, PM_FMA(w, PM_FMA(w, Lg7, Lg5), Lg3), Lg1);
+    double R = t2 + t1;
+    double dk = (double)k;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+/* x^y for x > 0 (fetch-relation seeding and e_T only) */
+PM_HD double pm_pow(double x, double y) { return pm_exp(y * pm_log(x)); }
+
+/* tanh(x) = sign(x) (1-t)/(1+t), t = exp(-2|x|)   (absolute accuracy ~1e-16) */
+PM_HD double pm_tanh(double x)
+{
+    if (x != x) return x;
+    double t = pm_exp(-2.0 * pm_fabs(x));
+    double r = (1.0 - t) / (1.0 + t);
+    return (x < 0.0) ? -r : r;
+}
+/* cosh(x) = (e + 1/e)/2, e = exp(|x|) (overflows to inf like libm beyond ~710) */
+PM_HD double pm_cosh(double x)
+{
+    if (x != x) return x;
+    double e = pm_exp(pm_fabs(x));
+    return 0.5 * (e + 1.0 / e);
+}
+/* logistic 1/(1+exp(-a)) : H_beta = 0.5 (1 + tanh(y)) = pm_logistic(2y) */
+PM_HD double pm_logistic(double a) { return 1.0 / (1.0 + pm_exp(-a)); }
+/* sech(x)^2 = 4t/(1+t)^2, t = exp(-2|x|) */
+PM_HD double pm_sech2(double x)
+{
+    double t = pm_exp(-2.0 * pm_fabs(x));
+    double d = 1.0 + t;
+    return (4.0 * t) / (d * d);
+}
+
+#endif /* PICLES_PMATH_H */

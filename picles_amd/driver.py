@@ -1,0 +1,183 @@
+"""HipModel: thin object wrapper over one `picles_ctx*` (one GPU, one y-slab).
+
+All compute happens in libpicles_hip.so (hand-written HIP kernels).  This module only moves
+host arrays across the C ABI.  If the library is missing or no HIP device exists, construction
+raises — there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+
+
+def _check(lib, h, rc, what):
+    if rc != 0:
+        msg = lib.picles_last_error(h)
+        raise K.PiclesError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def _col(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, order="F"))
+    if a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
+class HipModel:
+    def __init__(self, grid: K.PiclesGrid, phys: K.PiclesPhys, ode: K.PiclesOde, model: K.PiclesModel,
+                 mask=None, device: int = 0, halo_rows: int = 2, lib_path=None):
+        self.lib = K.load(lib_path)
+        self._mask = None
+        if mask is not None:
+            self._mask = np.ascontiguousarray(np.asarray(mask, dtype=np.int8).reshape(-1, order="F"))
+            grid.mask = self._mask.ctypes.data_as(K.c_int8_p)
+        if grid.j_end == 0 and grid.j_begin == 0:
+            grid.j_end = grid.Ny
+        self.Nx, self.Ny = grid.Nx, grid.Ny
+        self.j_begin, self.j_end = grid.j_begin, grid.j_end
+        self.ny_loc = self.j_end - self.j_begin
+        self.N = self.Nx * self.ny_loc
+        h = C.c_void_p()
+        rc = self.lib.picles_create(C.byref(grid), C.byref(phys), C.byref(ode), C.byref(model),
+                                    device, halo_rows, C.byref(h))
+        if rc != 0:
+            msg = self.lib.picles_last_error(None)
+            raise K.PiclesError(f"picles_create failed (rc={rc}): {msg.decode() if msg else '?'}")
+        self.h = h
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.picles_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        _check(self.lib, self.h, rc, what)
+
+    # ---- inputs ----
+    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0):
+        u0, v0 = _col(u0, self.N), _col(v0, self.N)
+        if u1 is not None:
+            u1, v1 = _col(u1, self.N), _col(v1, self.N)
+        self._ck(self.lib.picles_set_winds(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(u1), K.dptr(v1), t1),
+                 "picles_set_winds")
+
+    def seed(self, t0=0.0):
+        self._ck(self.lib.picles_seed(self.h, t0), "picles_seed")
+
+    # ---- stepping ----
+    def time_step(self, dt, flags=0):
+        self._ck(self.lib.picles_time_step(self.h, dt, flags), "picles_time_step")
+
+    def advance(self, dt, flags=0):
+        self._ck(self.lib.picles_advance(self.h, dt, flags), "picles_advance")
+
+    def remesh(self, dt):
+        self._ck(self.lib.picles_remesh(self.h, dt), "picles_remesh")
+
+    def tick(self, dt):
+        self._ck(self.lib.picles_tick(self.h, dt), "picles_tick")
+
+    def zero_state(self):
+        self._ck(self.lib.picles_zero_state(self.h), "picles_zero_state")
+
+    def sync(self):
+        self._ck(self.lib.picles_sync(self.h), "picles_sync")
+
+    @property
+    def clock(self):
+        return self.lib.picles_clock(self.h)
+
+    # ---- split phases (slab-partitioned step) ----
+    def begin_step(self, dt, flags=0):
+        self._ck(self.lib.picles_begin_step(self.h, dt, flags), "picles_begin_step")
+
+    def advance_rows(self, which, stream=None):
+        self._ck(self.lib.picles_advance_rows(self.h, which, stream), "picles_advance_rows")
+
+    def scatter_remesh(self, stream=None):
+        self._ck(self.lib.picles_scatter_remesh(self.h, stream), "picles_scatter_remesh")
+
+    def halo_send(self, side):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.picles_halo_send_dev(self.h, side, C.byref(p), C.byref(n)), "picles_halo_send_dev")
+        return p.value, n.value
+
+    def halo_recv(self, side):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.picles_halo_recv_dev(self.h, side, C.byref(p), C.byref(n)), "picles_halo_recv_dev")
+        return p.value, n.value
+
+    @property
+    def halo_rows(self):
+        return self.lib.picles_halo_rows(self.h)
+
+    def set_halo_rows(self, r):
+        self._ck(self.lib.picles_set_halo_rows(self.h, r), "picles_set_halo_rows")
+
+    # ---- outputs ----
+    def get_state(self):
+        s = np.empty(3 * self.N)
+        self._ck(self.lib.picles_get_state(self.h, K.dptr(s)), "picles_get_state")
+        return s.reshape((self.Nx, self.ny_loc, 3), order="F")
+
+    def set_state(self, s):
+        s = _col(s, 3 * self.N)
+        self._ck(self.lib.picles_set_state(self.h, K.dptr(s)), "picles_set_state")
+
+    def get_movie_state(self):
+        s = np.empty(3 * self.N)
+        self._ck(self.lib.picles_get_movie_state(self.h, K.dptr(s)), "picles_get_movie_state")
+        return s.reshape((self.Nx, self.ny_loc, 3), order="F")
+
+    def get_particles(self):
+        z = np.empty(5 * self.N)
+        on = np.empty(self.N, dtype=np.uint8)
+        bnd = np.empty(self.N, dtype=np.uint8)
+        st = np.empty(self.N, dtype=np.int32)
+        self._ck(self.lib.picles_get_particles(self.h, K.dptr(z), on.ctypes.data_as(K.c_uint8_p),
+                                               bnd.ctypes.data_as(K.c_uint8_p), st.ctypes.data_as(K.c_int32_p)),
+                 "picles_get_particles")
+        sh = (self.Nx, self.ny_loc)
+        return (z.reshape(sh + (5,), order="F"), on.reshape(sh, order="F"),
+                bnd.reshape(sh, order="F"), st.reshape(sh, order="F"))
+
+    def set_particles(self, z, on):
+        z = _col(z, 5 * self.N)
+        on = np.ascontiguousarray(np.asarray(on, dtype=np.uint8).reshape(-1, order="F"))
+        self._ck(self.lib.picles_set_particles(self.h, K.dptr(z), on.ctypes.data_as(K.c_uint8_p)),
+                 "picles_set_particles")
+
+    def scatter_particles(self, ij, xy, charge):
+        """generic push_to_grid! of a particle list (ij: (n,2) int, xy: (n,2), charge: (n,3))"""
+        ij = np.ascontiguousarray(np.asarray(ij, dtype=np.int32).T)
+        xy = np.ascontiguousarray(np.asarray(xy, dtype=np.float64).T)
+        ch = np.ascontiguousarray(np.asarray(charge, dtype=np.float64).T)
+        n = ij.shape[1]
+        self._ck(self.lib.picles_scatter_particles(self.h, n, ij.ctypes.data_as(K.c_int32_p), K.dptr(xy), K.dptr(ch)),
+                 "picles_scatter_particles")
+
+    def get_counters(self):
+        c = K.PiclesCounters()
+        self._ck(self.lib.picles_get_counters(self.h, C.byref(c)), "picles_get_counters")
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._ck(self.lib.picles_reset_counters(self.h), "picles_reset_counters")
+
+    def enable_timing(self, on=True):
+        self._ck(self.lib.picles_enable_timing(self.h, int(on)), "picles_enable_timing")
+
+    def get_timing(self):
+        t = K.PiclesTiming()
+        self._ck(self.lib.picles_get_timing(self.h, C.byref(t)), "picles_get_timing")
+        return t.as_dict()

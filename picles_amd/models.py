@@ -1,0 +1,187 @@
+"""WaveGrowth2D (reference: src/Models/WaveGrowthModels2D.jl:42-91,194-345).
+
+Same constructor keywords and the field names the stepper reads (`grid, State, clock, winds,
+ODEsettings, ODEdefaults, minimal_state, periodic_boundary, ocean_points, MovieState,
+FailedCollection`).  `State` lives in HBM; the attribute returns a host copy.
+`backend_factory` lets tests inject the CPU oracle behind the same surface; the default is
+the HIP library and nothing else.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _capi as K
+from . import fetch_relations as FetchRelations
+from .core_2D import ParticleDefaults
+from .grids import TwoDCartesianGridMesh, N_Periodic, make_boundary_lists
+from .particle_waves_v5 import ODESettings, ParticleSystem2D
+
+
+class Clock:
+    """stand-in for Oceananigans.Clock (time, iteration)"""
+
+    def __init__(self, time=0.0):
+        self.time = float(time)
+        self.iteration = 0
+
+    def __repr__(self):
+        return f"Clock(time={self.time}, iteration={self.iteration})"
+
+
+def build_structs(grid: TwoDCartesianGridMesh, ODEsys: ParticleSystem2D, ODEsets: ODESettings,
+                  ODEdefaults, minimal_state, periodic_boundary: bool, j_begin=0, j_end=None):
+    """WaveGrowth2D keyword arguments -> the four C structs of include/picles_hip.h"""
+    st = grid.stats
+    g = K.PiclesGrid()
+    g.Nx, g.Ny = int(st.Nx), int(st.Ny)
+    g.dx, g.dy = st.dx, st.dy
+    g.periodic_x = int(isinstance(st.Nx, N_Periodic))
+    g.periodic_y = int(isinstance(st.Ny, N_Periodic))
+    g.j_begin, g.j_end = j_begin, (g.Ny if j_end is None else j_end)
+    P = ODEsets.Parameters
+    idc = ODEsys.IDConstants
+    p = K.PiclesPhys()
+    p.r_g, p.C_alpha, p.C_phi, p.C_e, p.g = P["r_g"], P["C_α"], P["C_φ"], P["C_e"], P.get("g", 9.81)
+    p.gamma, p.q = ODEsys.γ, ODEsys.q
+    p.c_beta, p.c_D, p.c_e, p.c_alpha = idc.c_β, idc.c_D, idc.c_e, idc.c_alpha
+    p.propagation, p.input, p.dissipation = int(ODEsys.propagation), int(ODEsys.input), int(ODEsys.dissipation)
+    p.peak_shift, p.direction = int(ODEsys.peak_shift), int(ODEsys.direction)
+    o = K.PiclesOde()
+    if ODEsets.solver not in ("DP5",):
+        raise NotImplementedError(f"solver {ODEsets.solver!r}: the kernel implements DP5 (DESIGN.md)")
+    if not ODEsets.adaptive:
+        raise NotImplementedError("adaptive=false is not implemented")
+    o.abstol, o.reltol, o.dt0, o.dtmin = ODEsets.abstol, ODEsets.reltol, ODEsets.dt, ODEsets.dtmin
+    o.force_dtmin, o.solver, o.maxiters = int(ODEsets.force_dtmin), 0, int(ODEsets.maxiters)
+    o.log_energy_minimum, o.log_energy_maximum = ODEsets.log_energy_minimum, ODEsets.log_energy_maximum
+    o.wind_min_squared, o.timestep = ODEsets.wind_min_squared, ODEsets.timestep
+    m = K.PiclesModel()
+    m.periodic_boundary = int(periodic_boundary)
+    if ODEdefaults is None:
+        m.init_type = 0
+    else:
+        m.init_type = 1
+        m.default_particle[0], m.default_particle[1], m.default_particle[2] = \
+            ODEdefaults.lne, ODEdefaults.c̄_x, ODEdefaults.c̄_y
+    m.minimal_state[0], m.minimal_state[1] = minimal_state[0], minimal_state[1]
+    return g, p, o, m
+
+
+def sample_winds(winds, grid, t, rows=None):
+    """evaluate the user's u(x,y,t), v(x,y,t) on the mesh nodes — the only place user wind
+    callables run (the kernels read node-sampled fields)."""
+    x, y = grid.data.x, grid.data.y
+    if rows is not None:
+        x, y = x[:, rows[0]:rows[1]], y[:, rows[0]:rows[1]]
+
+    def ev(f):
+        try:
+            r = np.asarray(f(x, y, t), dtype=np.float64)
+            if r.shape != x.shape:
+                r = np.broadcast_to(r, x.shape)
+            return np.array(r, dtype=np.float64)
+        except Exception:
+            return np.vectorize(lambda a, b: float(f(a, b, t)), otypes=[np.float64])(x, y)
+    return ev(winds.u), ev(winds.v)
+
+
+def _hip_backend(g, p, o, m, mask, **kw):
+    from .driver import HipModel
+    return HipModel(g, p, o, m, mask=mask, **kw)
+
+
+class WaveGrowth2D:
+    def __init__(self, *, grid: TwoDCartesianGridMesh, winds, ODEsys: ParticleSystem2D, ODEvars=None,
+                 layers: int = 1, clock=None, ODEsets: ODESettings = None, ODEinit_type="wind_sea",
+                 minimal_particle=None, minimal_state=None, currents=None, periodic_boundary=True,
+                 boundary_type="same", CBsets=None, movie=False,
+                 backend_factory=None, backend_kwargs=None, winds_static=None):
+        if layers != 1:
+            raise NotImplementedError("layers > 1")
+        if isinstance(winds, dict):
+            winds = SimpleNamespace(**winds)
+        elif isinstance(winds, tuple):
+            winds = SimpleNamespace(u=winds[0], v=winds[1])
+        self.grid, self.winds, self.layers = grid, winds, layers
+        self.clock = clock if clock is not None else Clock(0.0)
+        self.dims = 2
+        self.ODEsystem, self.ODEsettings, self.ODEvars = ODEsys, ODEsets, ODEvars
+        if isinstance(ODEinit_type, ParticleDefaults):
+            self.ODEdefaults = ODEinit_type
+        elif ODEinit_type == "wind_sea":
+            self.ODEdefaults = None
+        elif ODEinit_type == "mininmal":  # (sic) WaveGrowthModels2D.jl:225
+            self.ODEdefaults = ParticleDefaults(-11.0, 1e-3, 0.0)
+        else:
+            raise ValueError("ODEinit_type must be either 'wind_sea','mininmal', or ParticleDefaults instance")
+        self.minimal_particle = (FetchRelations.MinimalParticle(2, 2, ODEsets.timestep)
+                                 if minimal_particle is None else minimal_particle)
+        self.minimal_state = (FetchRelations.MinimalState(2, 2, ODEsets.timestep)
+                              if minimal_state is None else list(minimal_state))
+        self.periodic_boundary = bool(periodic_boundary)
+        lists = make_boundary_lists(grid.data.mask)
+        if self.periodic_boundary:   # WaveGrowthModels2D.jl:256-270
+            self.ocean_points = lists.ocean + lists.grid_boundary
+            self.boundary_points = lists.land_boundary
+        else:
+            self.ocean_points = lists.ocean
+            self.boundary_points = lists.land_boundary + lists.grid_boundary
+        self.boundary = self.boundary_points if not self.periodic_boundary else []
+        self.boundary_defaults = self.ODEdefaults if boundary_type == "same" else None
+        self.currents = currents
+        self.movie = bool(movie)
+        self.MovieState = None
+        self.FailedCollection = []
+        # time-constant winds are detected by sampling two times unless the caller says so
+        self._winds_static = winds_static
+        g, p, o, m = build_structs(grid, ODEsys, ODEsets, self.ODEdefaults, self.minimal_state,
+                                   self.periodic_boundary)
+        factory = backend_factory or _hip_backend
+        self.backend = factory(g, p, o, m, grid.data.mask, **(backend_kwargs or {}))
+        self._wind_window = None
+
+    # ---- winds ----
+    def _is_static(self, dt):
+        if self._winds_static is None:
+            a = sample_winds(self.winds, self.grid, 0.0)
+            b = sample_winds(self.winds, self.grid, 0.37 * dt + 1.0)
+            c = sample_winds(self.winds, self.grid, 1234.5 * dt)
+            self._winds_static = bool(all(np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]) for k in (0, 1)))
+        return self._winds_static
+
+    def upload_winds(self, t, dt):
+        """node-sample the wind closures for the step [t, t+dt] (lerped in t by the kernel)"""
+        if self._is_static(dt):
+            if self._wind_window is None:
+                u, v = sample_winds(self.winds, self.grid, t)
+                self.backend.set_winds(u, v, t)
+                self._wind_window = (t, t)
+            return
+        if self._wind_window == (t, t + dt):
+            return
+        u0, v0 = sample_winds(self.winds, self.grid, t)
+        u1, v1 = sample_winds(self.winds, self.grid, t + dt)
+        self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
+        self._wind_window = (t, t + dt)
+
+    # ---- State lives on the device ----
+    @property
+    def State(self):
+        return self.backend.get_state()
+
+    @State.setter
+    def State(self, value):
+        self.backend.set_state(value)
+
+    @property
+    def ParticleCollection(self):
+        z, on, bnd, st = self.backend.get_particles()
+        return SimpleNamespace(u=z, on=on.astype(bool), boundary=bnd.astype(bool), status=st)
+
+
+def fields(model: WaveGrowth2D):
+    """WaveGrowthModels2D.jl:355"""
+    s = model.State
+    return SimpleNamespace(State=s, e=s[:, :, 0], m_x=s[:, :, 1], m_y=s[:, :, 2])

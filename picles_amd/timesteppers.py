@@ -1,0 +1,38 @@
+"""time_step! family (reference: src/Operators/TimeSteppers.jl:109-193,212-247).
+
+Python has no `!` in identifiers: time_step == time_step!, movie_time_step == movie_time_step!,
+time_step_advance == time_step!_advance, time_step_remesh == time_step!_remesh."""
+from __future__ import annotations
+
+from . import _capi as K
+
+
+def time_step(model, Δt: float, callbacks=None, debug=False, zero_first=False):
+    """advance all ocean_points particles, scatter, remesh, tick (TimeSteppers.jl:109-166).
+    `zero_first` fuses run!'s `State .= 0` (run.jl:75-79) into the scatter."""
+    model.upload_winds(model.clock.time, Δt)
+    model.backend.time_step(Δt, K.STEP_ZERO_FIRST if zero_first else 0)
+    model.clock.time += Δt
+    model.clock.iteration += 1
+
+
+def time_step_advance(model, Δt: float, FailedCollection=None):
+    """TimeSteppers.jl:168-180"""
+    model.upload_winds(model.clock.time, Δt)
+    model.backend.advance(Δt, 0)
+
+
+def time_step_remesh(model, Δt: float):
+    """TimeSteppers.jl:182-193 (does not tick)"""
+    model.upload_winds(model.clock.time, Δt)
+    model.backend.remesh(Δt)
+
+
+def movie_time_step(model, Δt: float, callbacks=None, debug=False):
+    """TimeSteppers.jl:212-247: State is snapshotted into MovieState between advance and remesh
+    and zeroed after the remesh."""
+    model.upload_winds(model.clock.time, Δt)
+    model.backend.time_step(Δt, K.STEP_MOVIE)
+    model.MovieState = model.backend.get_movie_state()
+    model.clock.time += Δt
+    model.clock.iteration += 1

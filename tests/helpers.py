@@ -1,0 +1,55 @@
+"""shared builders for the parity tests: the same WaveGrowth2D kwargs drive the HIP library
+(product) and the CPU oracle (checker)."""
+from __future__ import annotations
+
+import numpy as np
+
+import _oracle as O
+from picles_amd import models
+from picles_amd.simulations import Simulation, initialize_simulation, run
+from picles_amd.timesteppers import movie_time_step, time_step
+
+
+def oracle_factory(kind="pmath", order=1, threads=8):
+    def fac(g, p, o, m, mask, **kw):
+        return O.OracleModel(g, p, o, m, kind=kind, order=order, threads=threads, mask=mask)
+    return fac
+
+
+def make_model(cfg, backend="hip", **kw):
+    if backend == "hip":
+        return models.WaveGrowth2D(**cfg.model, backend_kwargs=kw or None)
+    kind, order = backend
+    return models.WaveGrowth2D(**cfg.model, backend_factory=oracle_factory(kind, order))
+
+
+def run_states(cfg, backend, n_steps=None):
+    """returns the list of State snapshots the reference's cash_store / MovieState would hold"""
+    m = make_model(cfg, backend)
+    n = cfg.n_steps if n_steps is None else n_steps
+    out = []
+    sim = Simulation(m, Δt=cfg.Δt, stop_time=cfg.Δt * (n - 1))
+    initialize_simulation(sim)
+    out.append(m.State.copy())
+    if cfg.mode == "run":
+        for _ in range(n):
+            time_step(m, cfg.Δt, zero_first=True)
+            out.append(m.State.copy())
+    else:
+        for _ in range(n):
+            movie_time_step(m, cfg.Δt)
+            out.append(m.MovieState.copy())
+    return m, out
+
+
+def assert_bitwise(a, b, what=""):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, what
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        bad = np.argwhere(~same)
+        k = tuple(bad[0])
+        rel = np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} values differ, first at {k}: "
+                             f"{a[k]!r} vs {b[k]!r}; max rel diff {rel:.3e}")
