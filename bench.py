@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/s of the PiCLES 2D particle-in-cell time step on N MI355X.
+
+A "step" is one model time step (advance + scatter + remesh) of the BASELINE.json metric
+workload: the 4096×4096 periodic Cartesian box, 1 particle per cell, constant winds (10,10),
+bench06 physics (configs.box4096), slab-partitioned over the N GPUs (strong scaling).
+Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+B_ALG = 64.0          # algorithmic HBM bytes per particle-step (SURVEY §8d / DESIGN.md)
+HBM_PEAK_GBPS = 8000.0
+FP64_PEAK_TFLOPS = 78.6
+FLOP_PER_RHS = 260.0  # fp64 operations of one kernel-order RHS incl. expanded div/sqrt/exp
+
+
+def cpu_baseline(args, W, K):
+    """time the CPU oracle (kind 'port': our C restatement, OpenMP over particles) on a bounded
+    sample of the same workload: an n×n periodic sub-box with identical physics and winds —
+    in a homogeneous periodic box every particle does the same work at step k as in the
+    4096² box — for the same W warm-up + K timed steps."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _oracle as O
+    from picles_amd import configs
+    from picles_amd.parallel import SlabModel
+    cores = os.cpu_count() or 1
+    threads = min(cores, args.cpu_threads) if args.cpu_threads else cores
+
+    def fac(g, p, o, m, mask, **kw):
+        return O.OracleModel(g, p, o, m, kind="pmath", order=1, threads=threads, mask=mask)
+
+    def run(n):
+        cfg = configs.box4096(n=n, U10=args.winds[0], V10=args.winds[1])
+        m = SlabModel(cfg.model, 0, 1, backend_factory=fac)
+        m.seed()
+        for _ in range(W):
+            m.time_step(cfg.Δt)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            m.time_step(cfg.Δt)
+        dt = time.perf_counter() - t0
+        return m.n_stepped * K / dt, dt
+
+    rate, dt = run(96)
+    n = 96
+    if dt < 0.4 * args.cpu_seconds:
+        n = int(min(1536, max(96, (args.cpu_seconds * rate / K) ** 0.5)))
+        n -= n % 8
+        rate, dt = run(n)
+    return {"value": rate, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n}x{n} periodic sub-box, same physics/winds, same {W}+{K} steps, {dt:.1f} s of CPU work "
+                      f"(C oracle, OpenMP {threads} threads on {cores} host cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=4096, help="grid nodes per side")
+    ap.add_argument("--winds", type=lambda s: tuple(float(x) for x in s.split(",")), default=(10.0, 10.0))
+    ap.add_argument("--halo", type=int, default=1, help="halo rows / pull reach for slabs")
+    ap.add_argument("--atomic", action="store_true", help="LDS-tiled atomic push scatter instead of the pull")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from picles_amd import configs, _capi as K
+    from picles_amd.parallel import SlabModel
+
+    cfg = configs.box4096(n=args.n, U10=args.winds[0], V10=args.winds[1])
+    model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo)
+    model.seed()
+    flags = K.STEP_ZERO_FIRST | (K.STEP_ATOMIC if args.atomic else 0)
+    W, Ksteps = args.warmup, args.steps
+    for _ in range(W):
+        model.time_step(cfg.Δt, flags)
+    model.sync()
+    model.backend.reset_counters()
+    model.backend.enable_timing(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        model.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(Ksteps):
+        model.time_step(cfg.Δt, flags)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    cnt = model.backend.get_counters()
+    tim = model.backend.get_timing()
+    n_local = model.n_stepped
+    vals = torch.tensor([elapsed, float(n_local), float(cnt["rhs_evals"]), float(cnt["halo_overflow"]),
+                         float(cnt["steps_accepted"]), float(cnt["steps_rejected"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = vals.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+    n_total = float(vals[1])
+    rhs_total = float(vals[2])
+    overflow = float(vals[3])
+    if overflow > 0:
+        raise SystemExit(f"halo overflow ({overflow} particles travelled beyond --halo {args.halo}): result invalid")
+
+    if rank == 0:
+        value = n_total * Ksteps / elapsed
+        adv_ms = tim["advance_ms"] / max(tim["advance_launches"], 1)
+        launches_per_step = max(tim["advance_launches"], 1) / Ksteps
+        # dominant kernel: k_advance.  algorithmic bytes per launch = B_ALG × particles a launch advances
+        per_launch = n_local / launches_per_step
+        achieved = B_ALG * per_launch / (adv_ms * 1e-3) / 1e9
+        rhs_per_ps = rhs_total / (n_total * Ksteps)
+        tflops = rhs_total * FLOP_PER_RHS / elapsed / 1e12
+        out = {
+            "metric": "particle_steps_per_sec",
+            "value": value,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": Ksteps,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed / Ksteps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"box{args.n}: {args.n}x{args.n} TwoDCartesianGridMesh, periodic, 1 particle/cell, "
+                            f"constant winds ({args.winds[0]:g},{args.winds[1]:g}), dx=2000 m, dt=600 s, bench06 physics "
+                            "(C_phi=0.04, gamma=0.88, DP5 abstol 1e-4 reltol 1e-3, lne_max=log 27)",
+                "grid": [args.n, args.n],
+                "particles": int(n_total),
+                "parallelism": f"y-slabs x{world}, forward halo of scatter records ({args.halo} row) over RCCL send/recv",
+                "scatter": "atomic-push" if args.atomic else "deterministic-pull",
+            },
+            "hbm_GBps_path": B_ALG * value / 1e9,
+            "roofline": {
+                "kernel": "k_advance",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "avg_launch_ms": adv_ms,
+                "note": "the fused RK advance is fp64-VALU bound, not HBM bound (DESIGN.md): see fp64",
+            },
+            "fp64": {
+                "rhs_evals_per_particle_step": rhs_per_ps,
+                "flop_per_rhs": FLOP_PER_RHS,
+                "achieved_tflops": tflops,
+                "peak_tflops": FP64_PEAK_TFLOPS * world,
+                "frac": tflops / (FP64_PEAK_TFLOPS * world),
+            },
+            "kernel_ms_per_step": {"advance": tim["advance_ms"] / Ksteps, "scatter_remesh": tim["scatter_ms"] / Ksteps,
+                                   "remesh": tim["remesh_ms"] / Ksteps},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, W, Ksteps)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

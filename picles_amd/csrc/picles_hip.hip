@@ -47,7 +47,9 @@ struct GridP {
     int Nx, Ny;            /* global */
     int periodic_x, periodic_y;
     int j_begin, ny_loc;
-    int R;                 /* scatter reach the pull kernel covers = ghost rows per side */
+    int R;                 /* ghost record rows per side (halo blocks); row offset of the records */
+    int Rp;                /* reach of the pull scatter: >0 fixed (slabs: = R), 0 = read the
+                              max_reach the advance kernel measured (single slab, no host sync) */
     int single_slab;       /* this context owns all rows: wrap in y is local */
     int ngroups;           /* 1, or 2 when grid-boundary (mask 3) particles are stepped */
 };
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
             int r = (bx < 0) ? -bx : bx + 1;
             int ry = (by < 0) ? -by : by + 1;
             reach = (r > ry) ? r : ry;
-            if (reach > G.R) overflow = 1;
+            if (G.Rp > 0 && reach > G.Rp) overflow = 1;
         }
         rr[5 * G.Nx + i] = flag;
     }
@@ -303,7 +305,10 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
         int j = jl + G.j_begin;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if (accum) { s0 = A.state[t]; s1 = A.state[t + A.n]; s2 = A.state[t + 2 * A.n]; }
-        const int R = G.R, W = 2 * R + 1;
+        int R = G.Rp;
+        if (R == 0) { R = A.cnt->max_reach; if (R < 1) R = 1; }
+        const int W = 2 * R + 1;
+        const int RO = G.R;   /* row offset of the own rows inside rec */
         int shx = 0, shy = 0;
         if (G.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= G.Nx) shx = G.Nx - i + R; }
         if (G.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= G.Ny) shy = G.Ny - j + R; }
@@ -317,9 +322,9 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
                 int row;
                 if (G.single_slab) {
                     int jw = jj; if (jw < 0) jw += G.Ny; else if (jw >= G.Ny) jw -= G.Ny;
-                    row = jw + R;
+                    row = jw + RO;
                 } else {
-                    row = jl + dj + R;
+                    row = jl + dj + RO;
                 }
                 const double *rr = rec_row(A, G, row);
                 for (int si = 0; si < W; si++) {
@@ -639,6 +644,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     G.j_begin = g->j_begin; G.ny_loc = g->j_end - g->j_begin;
     G.single_slab = (g->j_begin == 0 && g->j_end == g->Ny);
     G.R = halo_rows;
+    G.Rp = G.single_slab ? 0 : halo_rows;
     G.ngroups = 1;
 
     /* total mask (mask_utils.jl:38-55) for the local rows */
@@ -1021,6 +1027,7 @@ PX_EXPORT int32_t picles_set_halo_rows(picles_ctx *c, int32_t r)
     double *old = c->A.rec;
     c->A.rec = nullptr;
     c->G.R = r;
+    c->G.Rp = c->G.single_slab ? 0 : r;
     HIPCHK(c, hipMalloc(&c->A.rec, rec_bytes(c)));
     HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
     HIPCHK(c, hipMemcpyAsync((char *)c->A.rec + (size_t)r * row_b, (char *)old + (size_t)oldR * row_b,

@@ -1,0 +1,222 @@
+"""Slab-partitioned (multi-GPU) time step: one process per GPU, the 2D mesh cut into y-slabs.
+
+Per model step and rank (DESIGN.md "Multi-GPU"):
+    edge rows advance (stream E)  ->  halo blocks of scatter records to both neighbours
+                                      (torch.distributed P2P; backend "nccl" = RCCL over xGMI)
+    interior rows advance (stream M)            ... overlaps the exchange ...
+    pull-scatter + remesh of the own rows (stream M, after the ghost rows have landed)
+
+The halo blocks are contiguous row ranges of the record array inside libpicles_hip.so; they are
+wrapped zero-copy as torch tensors through __cuda_array_interface__, so RCCL reads and writes
+the library's own HBM.  With the gloo backend (CPU rehearsal of the N>1 path, or two ranks on
+one GPU) the blocks are staged through host memory instead.
+
+The reference has no counterpart (no NCCL/MPI anywhere); the forward halo of
+particle records replaces the unsynchronised shared-State scatter of TimeSteppers.jl:144-178.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+from .models import build_structs, sample_winds
+
+
+def slab_rows(Ny: int, world: int, rank: int):
+    """contiguous row range of `rank` (remainder rows go to the low ranks)"""
+    base, rem = divmod(Ny, world)
+    j0 = rank * base + min(rank, rem)
+    return j0, j0 + base + (1 if rank < rem else 0)
+
+
+class _DevBlock:
+    """exposes a raw device pointer to torch via the CUDA array interface"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes // 8,), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class HaloExchange:
+    """neighbour exchange of the record halo blocks with torch.distributed"""
+
+    def __init__(self, backend, rank: int, world: int, periodic_y: bool, dist=None, staged=None):
+        import torch
+        import torch.distributed as dist_mod
+        self.torch = torch
+        self.dist = dist if dist is not None else dist_mod
+        self.rank, self.world = rank, world
+        self.prev = rank - 1 if rank > 0 else (world - 1 if periodic_y else None)
+        self.next = rank + 1 if rank < world - 1 else (0 if periodic_y else None)
+        if world == 1:
+            self.prev = self.next = None
+        self.backend = backend
+        be = self.dist.get_backend() if world > 1 else "none"
+        self.staged = (be != "nccl") if staged is None else staged
+        self._bind()
+
+    def _bind(self):
+        torch = self.torch
+        self.blocks = {}
+        for name, fn in (("send_lo", lambda: self.backend.halo_send(0)), ("send_hi", lambda: self.backend.halo_send(1)),
+                         ("recv_lo", lambda: self.backend.halo_recv(0)), ("recv_hi", lambda: self.backend.halo_recv(1))):
+            ptr, nbytes = fn()
+            self.blocks[name] = (ptr, nbytes)
+        if self.staged:
+            n = self.blocks["send_lo"][1] // 8
+            self.host = {k: torch.empty(n, dtype=torch.float64) for k in self.blocks}
+            self._hip = C.CDLL("libamdhip64.so")
+            self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            self._hip.hipMemcpy.restype = C.c_int
+        else:
+            self.dev = {k: torch.as_tensor(_DevBlock(p, n), device="cuda") for k, (p, n) in self.blocks.items()}
+
+    def rebind(self):
+        self._bind()
+
+    def start(self):
+        """post the sends/recvs; returns the work handles (call inside the edge stream context)"""
+        if self.world == 1 or (self.prev is None and self.next is None):
+            return []
+        dist = self.dist
+        if self.staged:
+            for k in ("send_lo", "send_hi"):
+                p, n = self.blocks[k]
+                rc = self._hip.hipMemcpy(self.host[k].data_ptr(), p, n, 2)  # D2H
+                assert rc == 0, rc
+            T = self.host
+        else:
+            T = self.dev
+        ops = []
+        # order matters when prev == next (2 ranks, periodic): sends [hi->next, lo->prev],
+        # recvs [lo<-prev, hi<-next] pair up correctly on both sides
+        if self.next is not None:
+            ops.append(dist.P2POp(dist.isend, T["send_hi"], self.next))
+        if self.prev is not None:
+            ops.append(dist.P2POp(dist.isend, T["send_lo"], self.prev))
+        if self.prev is not None:
+            ops.append(dist.P2POp(dist.irecv, T["recv_lo"], self.prev))
+        if self.next is not None:
+            ops.append(dist.P2POp(dist.irecv, T["recv_hi"], self.next))
+        return dist.batch_isend_irecv(ops)
+
+    def finish(self, works):
+        for w in works:
+            w.wait()
+        if self.staged and works:
+            for k, present in (("recv_lo", self.prev is not None), ("recv_hi", self.next is not None)):
+                if present:
+                    p, n = self.blocks[k]
+                    rc = self._hip.hipMemcpy(p, self.host[k].data_ptr(), n, 1)  # H2D
+                    assert rc == 0, rc
+
+
+class SlabModel:
+    """One rank's slab of a WaveGrowth2D problem, stepped with halo exchange.
+
+    `cfg_model` are the WaveGrowth2D keyword arguments (picles_amd.configs)."""
+
+    def __init__(self, cfg_model: dict, rank: int, world: int, device: int = 0, halo_rows: int = 1,
+                 backend_factory=None, use_streams=True):
+        from . import fetch_relations as FetchRelations
+        grid, ODEsys, ODEsets = cfg_model["grid"], cfg_model["ODEsys"], cfg_model["ODEsets"]
+        self.grid, self.winds = grid, cfg_model["winds"]
+        self.rank, self.world = rank, world
+        self.periodic_boundary = bool(cfg_model.get("periodic_boundary", True))
+        ms = cfg_model.get("minimal_state")
+        self.minimal_state = FetchRelations.MinimalState(2, 2, ODEsets.timestep) if ms is None else list(ms)
+        init = cfg_model.get("ODEinit_type", "wind_sea")
+        defaults = None if isinstance(init, str) else init
+        Ny = int(grid.stats.Ny)
+        self.j0, self.j1 = slab_rows(Ny, world, rank)
+        g, p, o, m = build_structs(grid, ODEsys, ODEsets, defaults, self.minimal_state, self.periodic_boundary,
+                                   j_begin=self.j0, j_end=self.j1)
+        self.periodic_y = bool(g.periodic_y)
+        if backend_factory is None:
+            from .driver import HipModel
+            self.backend = HipModel(g, p, o, m, mask=grid.data.mask, device=device, halo_rows=halo_rows)
+        else:
+            self.backend = backend_factory(g, p, o, m, grid.data.mask, halo_rows=halo_rows)
+        self.static = bool(cfg_model.get("winds_static", False))
+        self.timestep = ODEsets.timestep
+        self.clock = 0.0
+        self._wind_window = None
+        self.n_stepped = self._count_stepped()
+        self.use_streams = use_streams and world > 1 and backend_factory is None
+        self.ex = HaloExchange(self.backend, rank, world, self.periodic_y) if world > 1 else None
+        if self.use_streams:
+            import torch
+            self.s_edge = torch.cuda.Stream()
+            self.s_main = torch.cuda.Stream()
+
+    def _count_stepped(self):
+        mk = self.grid.data.mask[:, self.j0:self.j1]
+        n = int((mk == 1).sum())
+        if self.periodic_boundary:
+            n += int((mk == 3).sum())
+        return n
+
+    def upload_winds(self, t, dt):
+        rows = (self.j0, self.j1)
+        if self.static:
+            if self._wind_window is None:
+                u, v = sample_winds(self.winds, self.grid, t, rows)
+                self.backend.set_winds(u, v, t)
+                self._wind_window = (t, t)
+            return
+        u0, v0 = sample_winds(self.winds, self.grid, t, rows)
+        u1, v1 = sample_winds(self.winds, self.grid, t + dt, rows)
+        self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
+
+    def seed(self):
+        self._wind_window = None
+        self.upload_winds(0.0, self.timestep)
+        self.backend.seed(0.0)
+        self.clock = 0.0
+
+    def time_step(self, dt, flags=K.STEP_ZERO_FIRST):
+        self.upload_winds(self.clock, dt)
+        b = self.backend
+        if self.world == 1:
+            b.time_step(dt, flags)
+        elif self.use_streams:
+            torch = self.ex.torch
+            b.begin_step(dt, flags)
+            with torch.cuda.stream(self.s_edge):
+                b.advance_rows(K.ROWS_EDGE, self.s_edge.cuda_stream)
+                works = self.ex.start()            # RCCL send/recv ordered after the edge kernel
+            b.advance_rows(K.ROWS_INTERIOR, self.s_main.cuda_stream)
+            with torch.cuda.stream(self.s_main):
+                self.ex.finish(works)              # s_main waits for the halo
+                b.scatter_remesh(self.s_main.cuda_stream)
+        else:
+            b.begin_step(dt, flags)
+            b.advance_rows(K.ROWS_EDGE)
+            b.sync()
+            works = self.ex.start()
+            b.advance_rows(K.ROWS_INTERIOR)
+            self.ex.finish(works)
+            b.scatter_remesh()
+        self.clock += dt
+
+    def sync(self):
+        self.backend.sync()
+        if self.use_streams:
+            self.s_edge.synchronize()
+            self.s_main.synchronize()
+
+    def get_state(self):
+        self.sync()
+        return self.backend.get_state()
+
+    def gather_state(self):
+        """all ranks' slabs concatenated along y (host; for tests)"""
+        s = self.get_state()
+        if self.world == 1:
+            return s
+        import torch.distributed as dist
+        parts = [None] * self.world
+        dist.all_gather_object(parts, s)
+        return np.concatenate(parts, axis=1)
