@@ -53,10 +53,12 @@ def cpu_baseline(args, W, K):
         dt = time.perf_counter() - t0
         return m.n_stepped * K / dt, dt
 
-    rate, dt = run(96)
     n = 96
-    if dt < 0.4 * args.cpu_seconds:
-        n = int(min(1536, max(96, (args.cpu_seconds * rate / K) ** 0.5)))
+    rate, dt = run(n)
+    for _ in range(4):   # grow the sample until it is ~cpu_seconds of work (bounded at 2048²)
+        if dt >= 0.5 * args.cpu_seconds or n >= 2048:
+            break
+        n = int(min(2048, max(n + 8, n * (args.cpu_seconds / max(dt, 1e-3)) ** 0.5)))
         n -= n % 8
         rate, dt = run(n)
     return {"value": rate, "unit": "particle-steps/s", "cores": threads, "kind": "port",
