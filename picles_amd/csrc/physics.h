@@ -98,6 +98,20 @@ struct PStats {
     int status;
 };
 
+/* node wind at absolute time t plus the quantities every RHS evaluation derives from it.
+ * For time-constant winds they are computed once per particle-step (same arithmetic, hoisted). */
+struct WindD {
+    double u, v, U2, U, invU2, halfU;
+};
+PM_HD void wind_derive(double u, double v, WindD &d)
+{
+    d.u = u;
+    d.v = v;
+    d.U2 = PM_FMA(u, u, v * v);
+    d.U = __builtin_sqrt(d.U2);
+    d.invU2 = 1.0 / d.U2;
+    d.halfU = 0.5 * d.U;
+}
 PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double &v)
 {
     if (P.wind_static) {
@@ -107,6 +121,14 @@ PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double 
         double s = (t - P.tw0) * P.inv_dtw;
         u = PM_FMA(w.du, s, w.u0);
         v = PM_FMA(w.dv, s, w.v0);
+    }
+}
+template <bool STATIC>
+PM_HD void wind_stage(const KParams &P, const Wind &w, double t, WindD &d)
+{
+    if (!STATIC) {
+        double s = (t - P.tw0) * P.inv_dtw;
+        wind_derive(PM_FMA(w.du, s, w.u0), PM_FMA(w.dv, s, w.v0), d);
     }
 }
 
@@ -175,20 +197,25 @@ PM_HD void index_weight(double zp, int &b, double &w_hi)
     w_hi = __builtin_rint((zp - fb) * 1e6) / 1e6;
 }
 
-/* RHS in kernel order.  invU2 = 1/U² is hoisted by the caller when the wind is time-constant. */
-PM_HD void rhs(const KParams &P, const Vec5 &z, double u, double v, Vec5 &d)
+/* RHS in kernel order: d(lne), d(c̄x), d(c̄y).  The position tendencies are c̄x/Δx, c̄y/Δy
+ * (linear in the state, independent of x,y) and are folded into the stepper.
+ * FAST = all five physics switches on and n == 2 (every reference script). */
+struct Vec3 {
+    double lne, cx, cy;
+};
+
+template <bool FAST>
+PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD &W, Vec3 &d)
 {
-    double cx = z.cx, cy = z.cy;
+    const double u = W.u, v = W.v;
     double c2 = PM_FMA(cx, cx, cy * cy);
     double cbar = __builtin_sqrt(c2);
-    double U2 = PM_FMA(u, u, v * v);
-    double U = __builtin_sqrt(U2);
     double cgp = cbar * P.inv_rg;
     double rc = 1.0 / cgp;
     double minv = (cgp >= 0.1) ? rc : 10.0;
     double wp = (0.5 * PK_G0) * minv;
     double kp = (0.25 * PK_G0) * (minv * minv);
-    double a = (0.5 * U) * rc;
+    double a = W.halfU * rc;
     double alpha = (a > 500.0) ? 500.0 : a;
     double gx = cx * P.inv_rg, gy = cy * P.inv_rg;
     double dot = PM_FMA(u, gx, v * gy);
@@ -198,45 +225,43 @@ PM_HD void rhs(const KParams &P, const Vec5 &z, double u, double v, Vec5 &d)
     double ap = (0.5 * dot) * sginv2;
     double ya = ap - 0.85;
     double H = 1.0 / (1.0 + pm_exp(P.neg2p * ya));
-    double t = pm_exp(-20.0 * pm_fabs(ya));
-    double t1 = 1.0 + t;
-    double D = 1.0 - (5.0 * t) / (t1 * t1);
-
+    /* Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).  For 20|ya| >= 40,
+     * 5t < 2^-54 and the expression rounds to exactly 1.0: skip the exp and the division. */
+    double targ = -20.0 * pm_fabs(ya);
+    double D = 1.0;
+    if (!(targ <= -40.0)) {
+        double t = pm_exp(targ);
+        double t1 = 1.0 + t;
+        D = 1.0 - (5.0 * t) / (t1 * t1);
+    }
     double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, E2 = 0.0;
-    if ((P.dissipation && P.n_is_2) || P.peak_shift) E2 = pm_exp(2.0 * z.lne);
-    if (P.input) It = (P.C_e * H) * (alpha * alpha);
-    if (P.dissipation) {
+    if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) E2 = pm_exp(2.0 * lne);
+    if (FAST || P.input) It = (P.C_e * H) * (alpha * alpha);
+    if (FAST || P.dissipation) {
         double ke = kp * P.inv_eT;
-        if (P.n_is_2) {
+        if (FAST || P.n_is_2) {
             double ke2 = ke * ke;
             Dt = E2 * (ke2 * ke2);
         } else {
-            Dt = pm_exp(P.n * z.lne) * pm_pow(ke, 2.0 * P.n);
+            Dt = pm_exp(P.n * lne) * pm_pow(ke, 2.0 * P.n);
         }
     }
-    if (P.peak_shift) {
+    if (FAST || P.peak_shift) {
         double k2 = kp * kp;
         Scg = ((P.C_alpha * D) * (k2 * k2)) * E2;
     }
-    if (P.direction) {
+    if (FAST || P.direction) {
         double s2;
-        if (U == 0.0 || cgp == 0.0)
+        if (W.U == 0.0 || cgp == 0.0)
             s2 = 0.0;
         else
-            s2 = ((2.0 * crs) * dot) * (rc2 * (1.0 / U2));
+            s2 = ((2.0 * crs) * dot) * (rc2 * W.invU2);
         Sd = (((alpha * alpha) * P.C_phi) * H) * s2;
     }
     double wrS = (wp * P.r_g) * Scg;
     d.lne = PM_FMA(wp, It - Dt, wrS);
     d.cx = PM_FMA(cy, Sd, -(cx * wrS));
     d.cy = -PM_FMA(cx, Sd, cy * wrS);
-    if (P.propagation) {
-        d.x = cx * P.inv_dx;
-        d.y = cy * P.inv_dy;
-    } else {
-        d.x = 0.0;
-        d.y = 0.0;
-    }
 }
 
 PM_HD double rms5(double a0, double a1, double a2, double a3, double a4)
@@ -249,38 +274,31 @@ PM_HD double rms5(double a0, double a1, double a2, double a3, double a4)
     return __builtin_sqrt(s * 0.2);
 }
 
-#define V5_MAP2(out, A, B, EXPR)                   \
-    {                                              \
-        { double a = (A).lne, b = (B).lne; (out).lne = (EXPR); } \
-        { double a = (A).cx,  b = (B).cx;  (out).cx  = (EXPR); } \
-        { double a = (A).cy,  b = (B).cy;  (out).cy  = (EXPR); } \
-        { double a = (A).x,   b = (B).x;   (out).x   = (EXPR); } \
-        { double a = (A).y,   b = (B).y;   (out).y   = (EXPR); } \
-    }
-
-/* ode_determine_initdt (Hairer–Wanner), = auto_dt_reset! after every remesh */
-PM_HD double init_dt(const KParams &P, const Wind &w, const Vec5 &u0, const Vec5 &f0, double t, PStats &st)
+/* ode_determine_initdt (Hairer–Wanner), = auto_dt_reset! after every remesh.
+ * f0 = (k1, kx, ky) is the RHS at (u0, t). */
+template <bool FAST, bool STATIC>
+PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, const Vec3 &k1, double kx, double ky,
+                     double ipx, double ipy, double t, PStats &st)
 {
-    Vec5 sk, q0, q1;
-    V5_MAP2(sk, u0, u0, PM_FMA(pm_fabs(a), P.reltol, P.abstol));
-    V5_MAP2(q0, u0, sk, a / b);
-    V5_MAP2(q1, f0, sk, a / b);
-    double d0 = rms5(q0.lne, q0.cx, q0.cy, q0.x, q0.y);
-    double d1 = rms5(q1.lne, q1.cx, q1.cy, q1.x, q1.y);
+    double sk0 = PM_FMA(pm_fabs(u0.lne), P.reltol, P.abstol);
+    double sk1 = PM_FMA(pm_fabs(u0.cx), P.reltol, P.abstol);
+    double sk2 = PM_FMA(pm_fabs(u0.cy), P.reltol, P.abstol);
+    double sk3 = PM_FMA(pm_fabs(u0.x), P.reltol, P.abstol);
+    double sk4 = PM_FMA(pm_fabs(u0.y), P.reltol, P.abstol);
+    double d0 = rms5(u0.lne / sk0, u0.cx / sk1, u0.cy / sk2, u0.x / sk3, u0.y / sk4);
+    double d1 = rms5(k1.lne / sk0, k1.cx / sk1, k1.cy / sk2, kx / sk3, ky / sk4);
     double dt0;
     if (d0 < 1e-5 || d1 < 1e-5) dt0 = 1e-6;
     else dt0 = 0.01 * (d0 / d1);
     if (dt0 < 10.0 * 2.220446049250313e-16) return 1e-6;
-    Vec5 u1, f1;
-    V5_MAP2(u1, f0, u0, PM_FMA(dt0, a, b));
-    double uw, vw;
-    wind_at(P, w, t + dt0, uw, vw);
-    rhs(P, u1, uw, vw, f1);
+    double l1 = PM_FMA(dt0, k1.lne, u0.lne), cx1 = PM_FMA(dt0, k1.cx, u0.cx), cy1 = PM_FMA(dt0, k1.cy, u0.cy);
+    Vec3 f1;
+    wind_stage<STATIC>(P, w, t + dt0, W);
+    rhs3<FAST>(P, l1, cx1, cy1, W, f1);
     st.rhs++;
-    Vec5 df;
-    V5_MAP2(df, f1, f0, a - b);
-    V5_MAP2(q1, df, sk, a / b);
-    double d2 = rms5(q1.lne, q1.cx, q1.cy, q1.x, q1.y) / dt0;
+    double f1x = cx1 * ipx, f1y = cy1 * ipy;
+    double d2 = rms5((f1.lne - k1.lne) / sk0, (f1.cx - k1.cx) / sk1, (f1.cy - k1.cy) / sk2,
+                     (f1x - kx) / sk3, (f1y - ky) / sk4) / dt0;
     double m = (d1 > d2) ? d1 : d2;
     double dt1;
     if (m <= 1e-15) {
@@ -296,18 +314,24 @@ PM_HD double init_dt(const KParams &P, const Wind &w, const Vec5 &u0, const Vec5
     return (P.dtmin > h) ? P.dtmin : h;
 }
 
-/* step!(integrator, DT, true): integrate z over [t_start, t_start+DT] */
+/* step!(integrator, DT, true): integrate z over [t_start, t_start+DT] with DP5(4).
+ * Only the stage derivatives of (lne, c̄x, c̄y) are kept; the x,y rows of the tableau are
+ * accumulated as the stages appear (same fma order as the full Butcher sums). */
+template <bool FAST, bool STATIC>
 PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &qold, double &dtn,
                          double t_start, double DT, PStats &st)
 {
-    Vec5 k1, k2, k3, k4, k5, k6, k7, g, un;
-    double uw, vw;
+    const double ipx = (FAST || P.propagation) ? P.inv_dx : 0.0;
+    const double ipy = (FAST || P.propagation) ? P.inv_dy : 0.0;
+    Vec3 k1, k2, k3, k4, k5, k6, k7;
+    WindD W;
     double tr = 0.0;
-    wind_at(P, w, t_start, uw, vw);
-    rhs(P, z, uw, vw, k1);
+    if (STATIC) wind_derive(w.u0, w.v0, W);
+    else wind_stage<false>(P, w, t_start, W);
+    rhs3<FAST>(P, z.lne, z.cx, z.cy, W, k1);
     st.rhs++;
     double dt = dtn;
-    if (!(dt > 0.0)) dt = init_dt(P, w, z, k1, t_start, st);
+    if (!(dt > 0.0)) dt = init_dt<FAST, STATIC>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, t_start, st);
     long long iter = 0;
     while (tr < DT) {
         iter++;
@@ -317,35 +341,59 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &qold,
         bool last = !(dt < rem);
         double h = last ? rem : dt;
         double t = t_start + tr;
+        double gl, gx, gy;      /* stage state (lne, c̄x, c̄y) */
+        double kx, ky;          /* stage x,y tendencies */
+        double ax, ay, ex, ey;  /* running Σ a7i k_i and Σ e_i k_i of the x,y components */
+        kx = z.cx * ipx; ky = z.cy * ipy;
+        ax = DP_A71 * kx; ay = DP_A71 * ky;
+        ex = DP_E1 * kx; ey = DP_E1 * ky;
         {
             double a21h = h * DP_A21;
-            V5_MAP2(g, k1, z, PM_FMA(a21h, a, b));
+            gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
         }
-        wind_at(P, w, PM_FMA(DP_C2, h, t), uw, vw);
-        rhs(P, g, uw, vw, k2);
+        wind_stage<STATIC>(P, w, PM_FMA(DP_C2, h, t), W);
+        rhs3<FAST>(P, gl, gx, gy, W, k2);
 #define ST3(c) PM_FMA(h, PM_FMA(DP_A32, k2.c, DP_A31 * k1.c), z.c)
-        g.lne = ST3(lne); g.cx = ST3(cx); g.cy = ST3(cy); g.x = ST3(x); g.y = ST3(y);
-        wind_at(P, w, PM_FMA(DP_C3, h, t), uw, vw);
-        rhs(P, g, uw, vw, k3);
+        gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
+        wind_stage<STATIC>(P, w, PM_FMA(DP_C3, h, t), W);
+        rhs3<FAST>(P, gl, gx, gy, W, k3);
+        kx = gx * ipx; ky = gy * ipy;
+        ax = PM_FMA(DP_A73, kx, ax); ay = PM_FMA(DP_A73, ky, ay);
+        ex = PM_FMA(DP_E3, kx, ex); ey = PM_FMA(DP_E3, ky, ey);
 #define ST4(c) PM_FMA(h, PM_FMA(DP_A43, k3.c, PM_FMA(DP_A42, k2.c, DP_A41 * k1.c)), z.c)
-        g.lne = ST4(lne); g.cx = ST4(cx); g.cy = ST4(cy); g.x = ST4(x); g.y = ST4(y);
-        wind_at(P, w, PM_FMA(DP_C4, h, t), uw, vw);
-        rhs(P, g, uw, vw, k4);
+        gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
+        wind_stage<STATIC>(P, w, PM_FMA(DP_C4, h, t), W);
+        rhs3<FAST>(P, gl, gx, gy, W, k4);
+        kx = gx * ipx; ky = gy * ipy;
+        ax = PM_FMA(DP_A74, kx, ax); ay = PM_FMA(DP_A74, ky, ay);
+        ex = PM_FMA(DP_E4, kx, ex); ey = PM_FMA(DP_E4, ky, ey);
 #define ST5(c) PM_FMA(h, PM_FMA(DP_A54, k4.c, PM_FMA(DP_A53, k3.c, PM_FMA(DP_A52, k2.c, DP_A51 * k1.c))), z.c)
-        g.lne = ST5(lne); g.cx = ST5(cx); g.cy = ST5(cy); g.x = ST5(x); g.y = ST5(y);
-        wind_at(P, w, PM_FMA(DP_C5, h, t), uw, vw);
-        rhs(P, g, uw, vw, k5);
+        gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
+        wind_stage<STATIC>(P, w, PM_FMA(DP_C5, h, t), W);
+        rhs3<FAST>(P, gl, gx, gy, W, k5);
+        kx = gx * ipx; ky = gy * ipy;
+        ax = PM_FMA(DP_A75, kx, ax); ay = PM_FMA(DP_A75, ky, ay);
+        ex = PM_FMA(DP_E5, kx, ex); ey = PM_FMA(DP_E5, ky, ey);
 #define ST6(c) PM_FMA(h, PM_FMA(DP_A65, k5.c, PM_FMA(DP_A64, k4.c, PM_FMA(DP_A63, k3.c, PM_FMA(DP_A62, k2.c, DP_A61 * k1.c)))), z.c)
-        g.lne = ST6(lne); g.cx = ST6(cx); g.cy = ST6(cy); g.x = ST6(x); g.y = ST6(y);
-        wind_at(P, w, t + h, uw, vw);
-        rhs(P, g, uw, vw, k6);
+        gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
+        wind_stage<STATIC>(P, w, t + h, W);
+        rhs3<FAST>(P, gl, gx, gy, W, k6);
+        kx = gx * ipx; ky = gy * ipy;
+        ax = PM_FMA(DP_A76, kx, ax); ay = PM_FMA(DP_A76, ky, ay);
+        ex = PM_FMA(DP_E6, kx, ex); ey = PM_FMA(DP_E6, ky, ey);
 #define ST7(c) PM_FMA(h, PM_FMA(DP_A76, k6.c, PM_FMA(DP_A75, k5.c, PM_FMA(DP_A74, k4.c, PM_FMA(DP_A73, k3.c, DP_A71 * k1.c)))), z.c)
-        un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy); un.x = ST7(x); un.y = ST7(y);
-        rhs(P, un, uw, vw, k7);
+        Vec5 un;
+        un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
+        un.x = PM_FMA(h, ax, z.x); un.y = PM_FMA(h, ay, z.y);
+        rhs3<FAST>(P, un.lne, un.cx, un.cy, W, k7);
         st.rhs += 6;
+        kx = un.cx * ipx; ky = un.cy * ipy;
+        ex = PM_FMA(DP_E7, kx, ex); ey = PM_FMA(DP_E7, ky, ey);
 #define ERRC(c) ((h * PM_FMA(DP_E7, k7.c, PM_FMA(DP_E6, k6.c, PM_FMA(DP_E5, k5.c, PM_FMA(DP_E4, k4.c, PM_FMA(DP_E3, k3.c, DP_E1 * k1.c)))))) / \
                  PM_FMA(pm_max(pm_fabs(z.c), pm_fabs(un.c)), P.reltol, P.abstol))
-        double EEst = rms5(ERRC(lne), ERRC(cx), ERRC(cy), ERRC(x), ERRC(y));
+        double EEst = rms5(ERRC(lne), ERRC(cx), ERRC(cy),
+                           (h * ex) / PM_FMA(pm_max(pm_fabs(z.x), pm_fabs(un.x)), P.reltol, P.abstol),
+                           (h * ey) / PM_FMA(pm_max(pm_fabs(z.y), pm_fabs(un.y)), P.reltol, P.abstol));
 #undef ST3
 #undef ST4
 #undef ST5

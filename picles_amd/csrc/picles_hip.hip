@@ -118,6 +118,7 @@ __device__ __forceinline__ double *rec_row(const Arrays &A, const GridP &G, int 
  * ---------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, const signed char *mask, double seed_T)
 {
+    pm_device_init();
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= A.n) return;
     int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
@@ -160,9 +161,11 @@ __global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, cons
  * registers.  Writes the particle's scatter record (ParticleToNode! inputs) instead of
  * scattering: the scatter itself is k_scatter / k_push_tiles.
  * ---------------------------------------------------------------------------------------- */
+template <bool FAST, bool STATIC>
 __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
                                                    int r0, int n0, int r1, int n1)
 {
+    pm_device_init();
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
     bool active = tid < na + nb;
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         int status = PICLES_ST_STEPPED;
         if (on) {
             adv = 1;
-            integrate_dp5(P, w, z, qold, dtn, t_start, DT, st);
+            integrate_dp5<FAST, STATIC>(P, w, z, qold, dtn, t_start, DT, st);
             status |= st.status;
         } else {
             double u, v;
@@ -298,6 +301,7 @@ template <bool REMESH>
 __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, int accum, int movie,
                                                    double clock, double DT)
 {
+    if (REMESH) pm_device_init();
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned int reseeds = 0;
     if (t < A.n) {
@@ -370,6 +374,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
 /* stand-alone time_step!_remesh (TimeSteppers.jl:182-193) */
 __global__ void __launch_bounds__(256) k_remesh(KParams P, GridP G, Arrays A, double clock, double DT)
 {
+    pm_device_init();
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned int reseeds = 0;
     if (t < A.n) {
@@ -830,7 +835,17 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     long long nt = (long long)(n0 + n1) * G.Nx;
     if (nt == 0) return 0;
     timing_begin(c, s, 0);
-    hipLaunchKernelGGL(k_advance, dim3(nblocks(nt, 256)), dim3(256), 0, s, c->P, c->G, c->A, c->clock, c->step_dt, r0, n0, r1, n1);
+    {
+        const KParams &P = c->P;
+        bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+        dim3 grid(nblocks(nt, 256)), block(256);
+#define LAUNCH_ADV(F, S) hipLaunchKernelGGL((k_advance<F, S>), grid, block, 0, s, c->P, c->G, c->A, c->clock, c->step_dt, r0, n0, r1, n1)
+        if (fast && P.wind_static) LAUNCH_ADV(true, true);
+        else if (fast) LAUNCH_ADV(true, false);
+        else if (P.wind_static) LAUNCH_ADV(false, true);
+        else LAUNCH_ADV(false, false);
+#undef LAUNCH_ADV
+    }
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
     if (which == PICLES_ROWS_EDGE && s != c->stream) {

@@ -9,7 +9,7 @@
  * multiply-add written explicitly (translation units are compiled with -ffp-contract=off),
  * so gcc on x86-64 and hipcc on gfx950 produce identical bits.
  *
- * Accuracy (measured in tests/test_pmath.py against glibc): exp, log < 1 ulp;
+ * Accuracy (measured in tests/test_pmath.py against glibc): exp < 2 ulp, log < 1 ulp;
  * pow(x,y) = exp(y log x) carries |y ln x| ulp (seeding only, compared at 1e-13).
  *
  * No reference counterpart: the reference calls Julia's libm-equivalents
@@ -52,39 +52,68 @@ PM_HD double pm_min(double a, double b) { return (a < b) ? a : b; }
 /* 2^k for -1022 <= k <= 1023 */
 PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
 
-/* exp(x): k = rint(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor/Horner, 2^k in two halves */
+/* 2^(j/32), j = 0..31, correctly rounded */
+#define PM_EXP_TAB_INIT                                                                              \
+    {1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577,           \
+     1.1143867425958924, 1.1387886347566916, 1.1637248587775775, 1.189207115002721,                 \
+     1.215247359980469, 1.241857812073484, 1.2690509571917332, 1.2968395546510096,                  \
+     1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951,                 \
+     1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407,                \
+     1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429,                  \
+     1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424,                 \
+     1.8741676341103, 1.9152065613971474, 1.9571441241754002}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+/* device: the table lives in LDS (per-lane index => ds_read_b64, no scalar path possible).
+ * Every kernel that evaluates pm_exp calls pm_device_init() first. */
+__device__ __constant__ const double PM_EXP_TAB_C[32] = PM_EXP_TAB_INIT;
+__device__ __forceinline__ double *pm_lds_tab(void)
+{
+    __shared__ double tab[32];
+    return tab;
+}
+__device__ __forceinline__ void pm_device_init(void)
+{
+    if (threadIdx.x < 32) pm_lds_tab()[threadIdx.x] = PM_EXP_TAB_C[threadIdx.x];
+    __syncthreads();
+}
+#define PM_EXP_TAB(j) (pm_lds_tab()[(j)])
+#else
+static const double PM_EXP_TAB_H[32] = PM_EXP_TAB_INIT;
+#define PM_EXP_TAB(j) (PM_EXP_TAB_H[(j)])
+#if defined(__HIPCC__)
+__device__ __forceinline__ void pm_device_init(void) {}   /* host pass of hipcc: declaration only */
+#endif
+#endif
+
+/* exp(x), branch-free: x = (32 m + j) ln2/32 + r, |r| <= ln2/64; exp(x) = 2^m * 2^(j/32) * P6(r).
+ * Out-of-range arguments are clamped and overflow / underflow through the final ldexp;
+ * NaN propagates through the polynomial. */
 PM_HD double pm_exp(double x)
 {
-    if (x != x) return x;
-    if (x > 709.782712893384) return pm_inf();
-    if (x < -745.1332191019412) return 0.0;
-    const double L2E = 1.4426950408889634074;
-    const double LN2_HI = 6.93147180369123816490e-01;
-    const double LN2_LO = 1.90821492927058770002e-10;
-    double k = __builtin_rint(x * L2E);
-    double r = PM_FMA(-k, LN2_HI, x);
-    r = PM_FMA(-k, LN2_LO, r);
-    double p = 1.6059043836821613e-10;            /* 1/13! */
-    p = PM_FMA(p, r, 2.08767569878681e-09);       /* 1/12! */
-    p = PM_FMA(p, r, 2.505210838544172e-08);      /* 1/11! */
-    p = PM_FMA(p, r, 2.755731922398589e-07);      /* 1/10! */
-    p = PM_FMA(p, r, 2.7557319223985893e-06);     /* 1/9!  */
-    p = PM_FMA(p, r, 2.48015873015873e-05);       /* 1/8!  */
-    p = PM_FMA(p, r, 1.984126984126984e-04);      /* 1/7!  */
-    p = PM_FMA(p, r, 1.388888888888889e-03);      /* 1/6!  */
-    p = PM_FMA(p, r, 8.333333333333333e-03);      /* 1/5!  */
-    p = PM_FMA(p, r, 4.1666666666666664e-02);     /* 1/4!  */
-    p = PM_FMA(p, r, 1.6666666666666666e-01);     /* 1/3!  */
+    const double R32 = 46.16624130844683;             /* 32/ln2 */
+    const double L_HI = 0.02166084938653512;          /* ln2/32, 32 trailing zero bits */
+    const double L_LO = 5.9631716539705866e-12;
+    x = (x > 710.0) ? 710.0 : x;
+    x = (x < -746.0) ? -746.0 : x;
+    double k = __builtin_rint(x * R32);
+    double r = PM_FMA(-k, L_HI, x);
+    r = PM_FMA(-k, L_LO, r);
+    int ki = (int)k;
+    int j = ki & 31;
+    int m = ki >> 5;
+    double p = 1.388888888888889e-03;                 /* 1/6! */
+    p = PM_FMA(p, r, 8.333333333333333e-03);          /* 1/5! */
+    p = PM_FMA(p, r, 4.1666666666666664e-02);         /* 1/4! */
+    p = PM_FMA(p, r, 1.6666666666666666e-01);         /* 1/3! */
     p = PM_FMA(p, r, 0.5);
     p = PM_FMA(p, r, 1.0);
     p = PM_FMA(p, r, 1.0);
-    int ki = (int)k;
-    int k1 = ki / 2;
-    int k2 = ki - k1;
-    return (p * pm_pow2i(k1)) * pm_pow2i(k2);
+    return __builtin_ldexp(PM_EXP_TAB(j) * p, m);
 }
 
-/* log(x): fdlibm-style  x = 2^k (1+f), s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)) */
+/* log(x), branch-free main path (fdlibm style: x = 2^k (1+f), s = f/(2+f),
+ * log(1+f) = f - hfsq + s (hfsq + R(s^2))), special cases selected at the end */
 PM_HD double pm_log(double x)
 {
     const double LN2_HI = 6.93147180369123816490e-01;
@@ -93,18 +122,11 @@ PM_HD double pm_log(double x)
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                  Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                  Lg7 = 1.479819860511658591e-01;
-    if (x != x) return x;
-    if (x < 0.0) return pm_nan();
-    if (x == 0.0) return -pm_inf();
-    if (pm_isinf(x)) return x;
-    int k = 0;
     uint64_t ux = pm_bits(x);
-    if ((ux >> 52) == 0) { /* subnormal: scale by 2^54 */
-        x = x * 18014398509481984.0;
-        ux = pm_bits(x);
-        k = -54;
-    }
-    /* normalise mantissa into [sqrt(2)/2, sqrt(2)) */
+    int sub = ((ux >> 52) == 0);                      /* +0 or positive subnormal */
+    double xs = sub ? x * 18014398509481984.0 : x;    /* 2^54 */
+    int k = sub ? -54 : 0;
+    ux = pm_bits(xs);
     uint32_t hx = (uint32_t)(ux >> 32);
     hx += 0x3ff00000u - 0x3fe6a09eu;
     k += (int)(hx >> 20) - 0x3ff;
@@ -120,7 +142,12 @@ PM_HD double pm_log(double x)
     double t2 = z * PM_FMA(w, PM_FMA(w, PM_FMA(w, Lg7, Lg5), Lg3), Lg1);
     double R = t2 + t1;
     double dk = (double)k;
-    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    double res = dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    res = (x == 0.0) ? -pm_inf() : res;
+    res = (x < 0.0) ? pm_nan() : res;
+    res = (x == pm_inf()) ? x : res;
+    res = (x != x) ? x : res;
+    return res;
 }
 
 /* x^y for x > 0 (fetch-relation seeding and e_T only) */
