@@ -1,0 +1,106 @@
+"""Host-side mirror of the reference interface: grid/mask classes, ocean_points, run! step
+count, movie_time_step! State semantics — computed here by the CPU oracle injected as backend
+(the product backend is the HIP library; see test_gpu_*.py)."""
+import numpy as np
+import pytest
+
+from picles_amd import configs, grids, models, fetch_relations as FR
+from picles_amd.simulations import Simulation, run, initialize_simulation
+from picles_amd.timesteppers import movie_time_step, time_step, time_step_advance, time_step_remesh
+from helpers import make_model, oracle_factory
+
+ORACLE = ("libm", 0)
+
+
+def test_make_boundaries_matches_reference_rules():
+    # mask_utils.jl:38-55: ring = 3 on non-periodic axes, land boundary = 2 next to ocean
+    mask = np.ones((6, 5), dtype=bool)
+    mask[2:4, 2] = False
+    tot = grids.make_boundaries(mask, grids.N_NonPeriodic(6), grids.N_Periodic(5))
+    assert (tot[0, :] == 3).all() and (tot[-1, :] == 3).all()
+    assert tot[2, 2] == 2 and tot[3, 2] == 2          # land cells touching ocean become 'land boundary'
+    assert tot[1, 1] == 1 and tot[2, 0] == 1          # periodic axis: no ring in y
+    g = grids.TwoDCartesianGridMesh(100e3, 51, 100e3, 51)
+    assert g.stats.dx == 2000.0 and int(g.stats.Nx) == 51
+    assert (g.data.mask[1:-1, 1:-1] == 1).all() and (g.data.mask[0] == 3).all()
+    assert g.data.x[3, 7] == 6000.0 and g.data.y[3, 7] == 14000.0
+
+
+def test_ocean_points_order_and_count():
+    cfg = configs.example_00_minimal()
+    m = make_model(cfg, ORACLE)
+    assert len(m.ocean_points) == 49 * 49                 # periodic_boundary = false: mask == 1 only
+    assert m.ocean_points[0] == (1, 1) and m.ocean_points[1] == (2, 1)   # column-major findall
+    assert m.backend.n_stepped == 49 * 49
+    cfg = configs.T04_2D_reg_test(periodic=True)
+    m = make_model(cfg, ORACLE)
+    assert len(m.ocean_points) == 31 * 31                 # ocean list, then the grid-boundary ring
+    assert m.ocean_points[29 * 29] == (0, 0)
+    assert m.backend.n_stepped == 31 * 31
+    _, _, bnd, _ = m.backend.get_particles()
+    assert not bnd.any()                                   # periodic model: only mask == 2 is 'boundary'
+
+
+def test_run_takes_one_step_past_stop_time():
+    cfg = configs.example_00_minimal(n=21, L=40e3)
+    m = make_model(cfg, ORACLE)
+    sim = Simulation(m, Δt=cfg.Δt, stop_time=cfg.stop_time)
+    run(sim, cash_store=True)
+    assert len(sim.store.store) == 14                      # initial + 13 steps for 2 h at 10 min (run.jl:113)
+    assert m.clock.time == 13 * 600.0
+    S0, S1 = sim.store.store[0], sim.store.store[1]
+    # initial State = seeded (e, m) on every non-land node, ring included (core_2D.jl:434-488)
+    ws = FR.get_initial_windsea(10.0, 10.0, 600.0)
+    assert S0[0, 0, 0] == pytest.approx(ws["E"], rel=1e-13) and S0[10, 10, 1] == pytest.approx(ws["m_x"], rel=1e-13)
+    # ring particles are never stepped: after a zero-first step the ring only holds scatter spill
+    assert S1[10, 10, 0] > S0[10, 10, 0]
+
+
+def test_movie_time_step_semantics():
+    cfg = configs.T04_2D_reg_test(n=15, L=56e3)
+    m = make_model(cfg, ORACLE)
+    sim = Simulation(m, Δt=cfg.Δt, stop_time=3600.0)
+    initialize_simulation(sim)
+    S_seed = m.State.copy()
+    movie_time_step(m, cfg.Δt)
+    M1 = m.MovieState.copy()
+    assert np.all(m.State == 0.0)                          # State zeroed after remesh (TimeSteppers.jl:245)
+    # first movie step scatters ON TOP of the seeded State (it is only zeroed after the step)
+    m2 = make_model(configs.T04_2D_reg_test(n=15, L=56e3), ORACLE)
+    initialize_simulation(Simulation(m2, Δt=cfg.Δt, stop_time=3600.0))
+    m2.backend.zero_state()
+    movie_time_step(m2, cfg.Δt)
+    assert np.allclose(M1, m2.MovieState + S_seed, rtol=1e-13, atol=1e-300)
+
+
+def test_split_advance_remesh_equals_time_step():
+    a = make_model(configs.example_00_minimal(n=17, L=32e3), ORACLE)
+    b = make_model(configs.example_00_minimal(n=17, L=32e3), ORACLE)
+    for m in (a, b):
+        initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
+    for _ in range(3):
+        a.backend.zero_state()
+        time_step(a, 600.0)
+        b.backend.zero_state()
+        time_step_advance(b, 600.0)
+        time_step_remesh(b, 600.0)
+        b.backend.tick(600.0); b.clock.time += 600.0
+    assert np.array_equal(a.State, b.State)
+    za, zb = a.backend.get_particles()[0], b.backend.get_particles()[0]
+    assert np.array_equal(za, zb)
+
+
+def test_calm_region_switches_particles_off_and_on():
+    """tests/T04_2D_on_off_particle_tests.jl idea: wind below sqrt(2) seeds 'off' particles;
+    they switch on when the wind picks up (mapping_2D.jl:172-185) and remesh branch D turns
+    starved particles off."""
+    cfg = configs.growing_decaying_winds(n=24, dx=2000.0, n_steps=4)
+    m = make_model(cfg, ORACLE)
+    initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    _, on0, _, _ = m.backend.get_particles()
+    assert not on0[:12].any() and on0[16:].all()           # calm half seeded off
+    for _ in range(4):
+        time_step(m, cfg.Δt, zero_first=True)
+    _, on1, _, st = m.backend.get_particles()
+    assert on1[16:-1, 1:-1].all()
+    assert m.backend.get_counters()["particles_advanced"] > 0

@@ -1,0 +1,43 @@
+"""pmath.h (deterministic exp/log/pow/tanh/cosh shared by the kernels and the pmath oracle)
+against glibc, through the oracle's math entry point."""
+import numpy as np
+
+import _oracle as O
+
+
+def _ulp_err(got, ref):
+    return np.abs(got - ref) / np.spacing(np.abs(ref))
+
+
+def test_exp_log_ulp():
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-700, 700, 200000)
+    assert _ulp_err(O.math_fn(0, x), np.exp(x)).max() < 2.5
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 100000)), 1 + rng.uniform(-0.3, 0.3, 100000)])
+    assert _ulp_err(O.math_fn(1, x), np.log(x)).max() <= 1.0   # numpy log itself is <= 0.5 ulp
+
+
+def test_special_values():
+    x = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, 1000.0, -746.0, -1e9, 5e-324, -1.0])
+    e = O.math_fn(0, x)
+    assert e[0] == 1.0 and e[1] == 1.0 and e[2] == np.inf and e[3] == 0.0 and np.isnan(e[4])
+    assert e[5] == np.inf and e[6] == np.inf and e[7] == 0.0 and e[8] == 0.0
+    l = O.math_fn(1, x)
+    assert l[0] == -np.inf and l[2] == np.inf and np.isnan(l[3]) and np.isnan(l[4]) and np.isnan(l[10])
+    assert abs(l[9] - np.log(5e-324)) < 1e-12
+    assert O.math_fn(0, np.array([-745.0]))[0] == np.exp(-745.0)
+
+
+def test_pow_tanh_cosh():
+    rng = np.random.default_rng(8)
+    x, y = rng.uniform(1e-6, 1e6, 50000), rng.uniform(-4, 4, 50000)
+    p = O.math_fn(2, x, y)
+    assert (np.abs(p - x ** y) / x ** y).max() < 2e-14
+    t = rng.uniform(-30, 30, 50000)
+    assert np.abs(O.math_fn(3, t) - np.tanh(t)).max() < 5e-16
+    assert (np.abs(O.math_fn(4, t) / np.cosh(t) - 1)).max() < 1e-15
+
+
+def test_libm_backend_is_glibc():
+    x = np.linspace(-5, 5, 101)
+    assert np.allclose(O.math_fn(0, x, kind="libm"), np.exp(x), rtol=4e-16, atol=0)
