@@ -97,9 +97,17 @@ typedef struct po_model {
     po_consts k;
     int order;
     int nthreads;
-    int Nx, Ny;
-    int64_t N;
-    int8_t *mask;
+    int Nx, Ny;                /* global node counts */
+    int j0, nyl;               /* slab: first owned row, number of owned rows */
+    int R;                     /* ghost record rows per side (slab stepping) */
+    int single_slab;
+    int ngroups;
+    int64_t N;                 /* Nx * nyl */
+    int8_t *mask;              /* local rows */
+    uint8_t *grp;              /* 0 not stepped, 1 ocean list, 2 grid-boundary list */
+    double *rec;               /* [(nyl+2R)][6][Nx] scatter records (pull / slab stepping) */
+    double step_dt;
+    int step_flags;
     double *state, *movie;     /* 3 planes */
     double *z;                 /* 5 planes */
     double *qold, *dtn;        /* controller memory, next dt (<0: auto_dt_reset!) */
@@ -661,6 +669,8 @@ static void po_remesh_particle(po_model *M, int64_t idx, double DT)
  * model: WaveGrowth2D constructor pieces (WaveGrowthModels2D.jl:194-345), mask classes
  * (mask_utils.jl:38-55), ocean_points (:256-270), check_boundary_point (core_2D.jl:360-366)
  * ---------------------------------------------------------------------------------------- */
+static size_t po_rec_doubles(const po_model *M) { return (size_t)(M->nyl + 2 * M->R) * 6 * M->Nx; }
+
 PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *p, const picles_ode *o,
                                        const picles_model *m, int32_t order, po_model **out)
 {
@@ -671,22 +681,31 @@ PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *
     M->order = order;
     M->nthreads = 1;
     M->Nx = g->Nx; M->Ny = g->Ny;
-    M->N = (int64_t)g->Nx * g->Ny;
+    M->j0 = g->j_begin;
+    M->nyl = (g->j_end > g->j_begin) ? g->j_end - g->j_begin : g->Ny;
+    if (g->j_end <= g->j_begin) { M->j0 = 0; M->g.j_begin = 0; M->g.j_end = g->Ny; }
+    M->single_slab = (M->j0 == 0 && M->nyl == M->Ny);
+    M->R = 1;
+    M->N = (int64_t)M->Nx * M->nyl;
     int64_t N = M->N;
     po_derive(p, g->dx, g->dy, &M->k);
     M->mask = (int8_t *)malloc(N);
-    if (g->mask) {
-        memcpy(M->mask, g->mask, N);
-    } else { /* make_boundaries(ones) : grid-boundary ring on non-periodic axes */
-        memset(M->mask, 1, N);
-        for (int j = 0; j < M->Ny; j++)
-            for (int i = 0; i < M->Nx; i++) {
+    int any3 = 0;
+    for (int j = 0; j < M->Ny; j++)
+        for (int i = 0; i < M->Nx; i++) {
+            int8_t mk;
+            if (g->mask) mk = g->mask[i + (int64_t)M->Nx * j];
+            else { /* make_boundaries(ones): grid-boundary ring on non-periodic axes */
                 int ring = (!g->periodic_x && (i == 0 || i == M->Nx - 1)) ||
                            (!g->periodic_y && (j == 0 || j == M->Ny - 1));
-                if (ring) M->mask[i + (int64_t)M->Nx * j] = 3;
+                mk = ring ? 3 : 1;
             }
-    }
-    M->g.mask = M->mask;
+            if (mk == 3) any3 = 1;
+            int jl = j - M->j0;
+            if (jl >= 0 && jl < M->nyl) M->mask[i + (int64_t)M->Nx * jl] = mk;
+        }
+    M->g.mask = NULL;
+    M->ngroups = (any3 && m->periodic_boundary) ? 2 : 1;
     M->state = (double *)calloc(3 * N, 8);
     M->movie = (double *)calloc(3 * N, 8);
     M->z = (double *)calloc(5 * N, 8);
@@ -694,16 +713,18 @@ PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *
     M->dtn = (double *)calloc(N, 8);
     M->on = (uint8_t *)calloc(N, 1);
     M->bnd = (uint8_t *)calloc(N, 1);
+    M->grp = (uint8_t *)calloc(N, 1);
     M->status = (int32_t *)calloc(N, 4);
     M->u0 = (double *)calloc(N, 8); M->v0 = (double *)calloc(N, 8);
     M->u1 = (double *)calloc(N, 8); M->v1 = (double *)calloc(N, 8);
+    M->rec = (double *)calloc(po_rec_doubles(M), 8);
     M->wind_static = 1;
     /* ocean_points: findall(mask .== 1) [then findall(mask .== 3) if periodic_boundary], column-major */
     M->steplist = (int64_t *)malloc(N * 8);
     int64_t ns = 0;
-    for (int64_t n = 0; n < N; n++) if (M->mask[n] == 1) M->steplist[ns++] = n;
+    for (int64_t n = 0; n < N; n++) if (M->mask[n] == 1) { M->steplist[ns++] = n; M->grp[n] = 1; }
     if (m->periodic_boundary)
-        for (int64_t n = 0; n < N; n++) if (M->mask[n] == 3) M->steplist[ns++] = n;
+        for (int64_t n = 0; n < N; n++) if (M->mask[n] == 3) { M->steplist[ns++] = n; M->grp[n] = 2; }
     M->n_step = ns;
     for (int64_t n = 0; n < N; n++)
         M->bnd[n] = m->periodic_boundary ? (M->mask[n] == 2) : (M->mask[n] >= 2);
@@ -714,7 +735,7 @@ PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *
 PO_EXPORT int32_t picles_oracle_destroy(po_model *M)
 {
     if (!M) return 0;
-    free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->dtn);
+    free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->dtn); free(M->grp); free(M->rec);
     free(M->on); free(M->bnd); free(M->status); free(M->steplist);
     free(M->u0); free(M->v0); free(M->u1); free(M->v1);
     free(M);
@@ -747,6 +768,7 @@ PO_EXPORT int32_t picles_oracle_seed(po_model *M, double t0)
 {
     int64_t N = M->N;
     M->clock = t0;
+    memset(M->rec, 0, po_rec_doubles(M) * 8);
     memset(M->state, 0, 3 * N * 8);
     memset(&M->cnt, 0, sizeof(M->cnt));
     for (int64_t n = 0; n < N; n++) {
@@ -796,6 +818,7 @@ PO_EXPORT int32_t picles_oracle_seed(po_model *M, double t0)
 /* time_step!_advance (TimeSteppers.jl:168-180) */
 PO_EXPORT int32_t picles_oracle_advance(po_model *M, double DT)
 {
+    if (!M->single_slab) return -5; /* the sequential push needs the whole grid */
     uint64_t rhs = 0, acc = 0, rej = 0, adv = 0;
     int64_t ns = M->n_step;
 #ifdef _OPENMP
@@ -883,6 +906,183 @@ PO_EXPORT int32_t picles_oracle_get_counters(po_model *M, picles_counters *c) { 
 PO_EXPORT int32_t picles_oracle_get_mask(po_model *M, int8_t *mask) { memcpy(mask, M->mask, M->N); return 0; }
 PO_EXPORT int64_t picles_oracle_n_stepped(po_model *M) { return M->n_step; }
 PO_EXPORT double picles_oracle_e_T(po_model *M) { return M->k.e_T; }
+
+/* ------------------------------------------------------------------------------------------
+ * Slab stepping with a PULL scatter — CPU restatement of the algorithm the HIP kernels run
+ * (DESIGN.md "k_scatter"): every particle leaves a scatter record (e, m_x, m_y, x, y, group);
+ * node (i,j) then visits its (2R+1)² candidate sources in the reference's sequential order
+ * (ocean list before grid-boundary list, each column-major; periodic images sorted by their
+ * wrapped index) and adds (wx*wy)*charge of the corner that lands on it.  On a single slab this
+ * must reproduce picles_oracle_advance's sequential push bit for bit (tests/test_oracle_pull.py);
+ * with ghost record rows filled by the neighbours it is the multi-GPU step.
+ * ---------------------------------------------------------------------------------------- */
+static inline double *po_rec_row(po_model *M, int row) { return M->rec + (size_t)row * 6 * M->Nx; }
+
+PO_EXPORT int32_t picles_oracle_set_halo_rows(po_model *M, int32_t r)
+{
+    if (r < 1) return -1;
+    M->R = r;
+    free(M->rec);
+    M->rec = (double *)calloc(po_rec_doubles(M), 8);
+    return 0;
+}
+PO_EXPORT int32_t picles_oracle_halo_rows(const po_model *M) { return M->R; }
+
+PO_EXPORT int32_t picles_oracle_begin_step(po_model *M, double dt, int32_t flags)
+{
+    M->step_dt = dt;
+    M->step_flags = flags;
+    M->cnt.max_reach = 0;
+    return 0;
+}
+
+static void po_write_record(po_model *M, int64_t idx, int *reach_out, int *overflow)
+{
+    int i = (int)(idx % M->Nx), jl = (int)(idx / M->Nx);
+    double *rr = po_rec_row(M, jl + M->R);
+    double z[5];
+    for (int c = 0; c < 5; c++) z[c] = M->z[idx + c * M->N];
+    double flag = 0.0;
+    if (M->on[idx] && isfinite(z[3]) && isfinite(z[4])) {
+        double c3[3];
+        po_particle_to_charge(z, c3);
+        rr[i] = c3[0]; rr[M->Nx + i] = c3[1]; rr[2 * M->Nx + i] = c3[2]; rr[3 * M->Nx + i] = z[3]; rr[4 * M->Nx + i] = z[4];
+        flag = (double)M->grp[idx];
+        int64_t xi[2], yi[2];
+        double w[2];
+        po_index_weight(z[3], 0, xi, w);
+        po_index_weight(z[4], 0, yi, w);
+        int r = (int)((xi[0] < 0) ? -xi[0] : xi[0] + 1);
+        int ry = (int)((yi[0] < 0) ? -yi[0] : yi[0] + 1);
+        if (ry > r) r = ry;
+        if (r > *reach_out) *reach_out = r;
+        if (!M->single_slab && r > M->R) (*overflow)++;
+    }
+    rr[5 * M->Nx + i] = flag;
+}
+
+PO_EXPORT int32_t picles_oracle_advance_rows(po_model *M, int32_t which)
+{
+    int R = M->R, r0 = 0, n0 = 0, r1 = 0, n1 = 0;
+    int small = M->nyl <= 2 * R;
+    if (which == PICLES_ROWS_ALL) { n0 = M->nyl; }
+    else if (which == PICLES_ROWS_EDGE) { if (small) n0 = M->nyl; else { n0 = R; r1 = M->nyl - R; n1 = R; } }
+    else if (which == PICLES_ROWS_INTERIOR) { if (small) return 0; r0 = R; n0 = M->nyl - 2 * R; }
+    else return -2;
+    uint64_t rhs = 0, acc = 0, rej = 0, adv = 0;
+    int reach = 0, overflow = 0;
+    for (int part = 0; part < 2; part++) {
+        int ra = part ? r1 : r0, na = part ? n1 : n0;
+        int64_t a = (int64_t)ra * M->Nx, b = (int64_t)(ra + na) * M->Nx;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(M->nthreads) reduction(+ : rhs, acc, rej, adv)
+#endif
+        for (int64_t idx = a; idx < b; idx++) {
+            if (!M->grp[idx]) continue;
+            po_pstats st = {0, 0, 0, 0};
+            int was_on = M->on[idx];
+            po_advance_particle(M, idx, M->step_dt, &st);
+            rhs += st.rhs; acc += st.acc; rej += st.rej; adv += was_on ? 1 : 0;
+        }
+        for (int64_t idx = a; idx < b; idx++) {
+            if (!M->grp[idx]) continue;
+            int st = M->status[idx];
+            if (st & (PICLES_ST_RESEED_NAN | PICLES_ST_RESEED_INF | PICLES_ST_SWITCHED_ON)) M->cnt.reseeds++;
+            if (st & PICLES_ST_CLAMPED) M->cnt.clamps++;
+            if (st & PICLES_ST_MAXITERS) M->cnt.maxiters_hits++;
+            po_write_record(M, idx, &reach, &overflow);
+        }
+    }
+    M->cnt.rhs_evals += rhs; M->cnt.steps_accepted += acc; M->cnt.steps_rejected += rej;
+    M->cnt.particles_advanced += adv;
+    M->cnt.halo_overflow += overflow;
+    if (reach > M->cnt.max_reach) M->cnt.max_reach = reach;
+    return 0;
+}
+
+static void po_pull_node(po_model *M, int i, int jl, int R, int accum, double s[3])
+{
+    int j = jl + M->j0, Nx = M->Nx, Ny = M->Ny, W = 2 * R + 1;
+    int64_t t = i + (int64_t)Nx * jl;
+    s[0] = accum ? M->state[t] : 0.0;
+    s[1] = accum ? M->state[t + M->N] : 0.0;
+    s[2] = accum ? M->state[t + 2 * M->N] : 0.0;
+    int shx = 0, shy = 0;
+    if (M->g.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= Nx) shx = Nx - i + R; }
+    if (M->g.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= Ny) shy = Ny - j + R; }
+    for (int grp = 1; grp <= M->ngroups; grp++)
+        for (int sj = 0; sj < W; sj++) {
+            int dj = (sj + shy) % W - R;
+            int jj = j + dj;
+            if (!M->g.periodic_y && (jj < 0 || jj >= Ny)) continue;
+            int row = M->single_slab ? (int)po_wrap(jj, Ny) + M->R : jl + dj + M->R;
+            const double *rr = po_rec_row(M, row);
+            for (int si = 0; si < W; si++) {
+                int di = (si + shx) % W - R;
+                int ii = i + di;
+                if (ii < 0 || ii >= Nx) { if (!M->g.periodic_x) continue; ii = (int)po_wrap(ii, Nx); }
+                if (rr[5 * Nx + ii] != (double)grp) continue;
+                int64_t xi[2], yi[2];
+                double xw[2], yw[2];
+                po_index_weight(rr[3 * Nx + ii], 0, xi, xw);
+                po_index_weight(rr[4 * Nx + ii], 0, yi, yw);
+                int ax = (int)(-di - xi[0]), ay = (int)(-dj - yi[0]);
+                if (ax < 0 || ax > 1 || ay < 0 || ay > 1) continue;
+                double w = xw[ax] * yw[ay];
+                s[0] += w * rr[ii];
+                s[1] += w * rr[Nx + ii];
+                s[2] += w * rr[2 * Nx + ii];
+            }
+        }
+}
+
+/* pull-scatter own rows (+ optional remesh, MovieState, tick) */
+PO_EXPORT int32_t picles_oracle_scatter_rows(po_model *M, int32_t do_remesh)
+{
+    int flags = M->step_flags;
+    int movie = (flags & PICLES_STEP_MOVIE) != 0 && do_remesh;
+    int accum = (flags & PICLES_STEP_ZERO_FIRST) ? 0 : 1;
+    int R = M->single_slab ? (M->cnt.max_reach > 1 ? M->cnt.max_reach : 1) : M->R;
+    double *ns = (double *)malloc(3 * M->N * 8);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(M->nthreads)
+#endif
+    for (int64_t t = 0; t < M->N; t++) {
+        double s[3];
+        po_pull_node(M, (int)(t % M->Nx), (int)(t / M->Nx), R, accum, s);
+        ns[t] = s[0]; ns[t + M->N] = s[1]; ns[t + 2 * M->N] = s[2];
+    }
+    memcpy(M->state, ns, 3 * M->N * 8);
+    free(ns);
+    if (do_remesh) {
+        if (movie) memcpy(M->movie, M->state, 3 * M->N * 8);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(M->nthreads)
+#endif
+        for (int64_t t = 0; t < M->N; t++)
+            if (M->grp[t]) po_remesh_particle(M, t, M->step_dt);
+        if (movie) memset(M->state, 0, 3 * M->N * 8);
+        M->clock += M->step_dt;
+    }
+    return 0;
+}
+
+PO_EXPORT int32_t picles_oracle_halo_ptr(po_model *M, int32_t side, int32_t send, double **ptr, size_t *bytes)
+{
+    size_t row_d = (size_t)6 * M->Nx;
+    int row = send ? (side == 0 ? M->R : M->nyl) : (side == 0 ? 0 : M->nyl + M->R);
+    *ptr = M->rec + (size_t)row * row_d;
+    *bytes = (size_t)M->R * row_d * 8;
+    return 0;
+}
+
+/* time_step! through the pull path (single slab) — must equal picles_oracle_time_step bitwise */
+PO_EXPORT int32_t picles_oracle_time_step_pull(po_model *M, double dt, int32_t flags)
+{
+    picles_oracle_begin_step(M, dt, flags);
+    picles_oracle_advance_rows(M, PICLES_ROWS_ALL);
+    return picles_oracle_scatter_rows(M, 1);
+}
 
 /* ---- single-function entry points for unit tests ---------------------------------------- */
 PO_EXPORT void picles_oracle_windsea(double U, double V, double T, double out[3]) { po_windsea(U, V, T, out); }

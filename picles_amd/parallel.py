@@ -42,7 +42,7 @@ class _DevBlock:
 class HaloExchange:
     """neighbour exchange of the record halo blocks with torch.distributed"""
 
-    def __init__(self, backend, rank: int, world: int, periodic_y: bool, dist=None, staged=None):
+    def __init__(self, backend, rank: int, world: int, periodic_y: bool, dist=None, staged=None, host_blocks=False):
         import torch
         import torch.distributed as dist_mod
         self.torch = torch
@@ -55,6 +55,7 @@ class HaloExchange:
         self.backend = backend
         be = self.dist.get_backend() if world > 1 else "none"
         self.staged = (be != "nccl") if staged is None else staged
+        self.host_blocks = host_blocks      # the halo blocks are host memory (CPU rehearsal backend)
         self._bind()
 
     def _bind(self):
@@ -67,9 +68,13 @@ class HaloExchange:
         if self.staged:
             n = self.blocks["send_lo"][1] // 8
             self.host = {k: torch.empty(n, dtype=torch.float64) for k in self.blocks}
-            self._hip = C.CDLL("libamdhip64.so")
-            self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            self._hip.hipMemcpy.restype = C.c_int
+            if self.host_blocks:
+                self._copy = lambda dst, src, n, kind: (C.memmove(dst, src, n), 0)[1]
+            else:
+                hip = C.CDLL("libamdhip64.so")
+                hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                hip.hipMemcpy.restype = C.c_int
+                self._copy = hip.hipMemcpy
         else:
             self.dev = {k: torch.as_tensor(_DevBlock(p, n), device="cuda") for k, (p, n) in self.blocks.items()}
 
@@ -84,7 +89,7 @@ class HaloExchange:
         if self.staged:
             for k in ("send_lo", "send_hi"):
                 p, n = self.blocks[k]
-                rc = self._hip.hipMemcpy(self.host[k].data_ptr(), p, n, 2)  # D2H
+                rc = self._copy(self.host[k].data_ptr(), p, n, 2)  # D2H
                 assert rc == 0, rc
             T = self.host
         else:
@@ -109,7 +114,7 @@ class HaloExchange:
             for k, present in (("recv_lo", self.prev is not None), ("recv_hi", self.next is not None)):
                 if present:
                     p, n = self.blocks[k]
-                    rc = self._hip.hipMemcpy(p, self.host[k].data_ptr(), n, 1)  # H2D
+                    rc = self._copy(p, self.host[k].data_ptr(), n, 1)  # H2D
                     assert rc == 0, rc
 
 
@@ -145,7 +150,8 @@ class SlabModel:
         self._wind_window = None
         self.n_stepped = self._count_stepped()
         self.use_streams = use_streams and world > 1 and backend_factory is None
-        self.ex = HaloExchange(self.backend, rank, world, self.periodic_y) if world > 1 else None
+        self.ex = (HaloExchange(self.backend, rank, world, self.periodic_y, host_blocks=backend_factory is not None)
+                   if world > 1 else None)
         if self.use_streams:
             import torch
             self.s_edge = torch.cuda.Stream()

@@ -62,6 +62,13 @@ def lib(kind: str = "libm") -> C.CDLL:
         "picles_oracle_is_pmath": (C.c_int32, []),
         "picles_oracle_has_openmp": (C.c_int32, []),
         "picles_oracle_math": (None, [C.c_int32, C.c_int64, DP, DP, DP]),
+        "picles_oracle_set_halo_rows": (C.c_int32, [VP, C.c_int32]),
+        "picles_oracle_halo_rows": (C.c_int32, [VP]),
+        "picles_oracle_begin_step": (C.c_int32, [VP, D, C.c_int32]),
+        "picles_oracle_advance_rows": (C.c_int32, [VP, C.c_int32]),
+        "picles_oracle_scatter_rows": (C.c_int32, [VP, C.c_int32]),
+        "picles_oracle_halo_ptr": (C.c_int32, [VP, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+        "picles_oracle_time_step_pull": (C.c_int32, [VP, D, C.c_int32]),
     }
     for n, (r, a) in sig.items():
         f = getattr(L, n)
@@ -89,21 +96,29 @@ class OracleModel:
     """Same call surface as picles_amd.driver.HipModel, computed by the CPU oracle."""
 
     def __init__(self, grid: K.PiclesGrid, phys: K.PiclesPhys, ode: K.PiclesOde, model: K.PiclesModel,
-                 kind: str = "pmath", order: int = 1, threads: int = 1, mask=None):
+                 kind: str = "pmath", order: int = 1, threads: int = 1, mask=None, halo_rows: int = 1,
+                 pull: bool = False):
         self.L = lib(kind)
-        self.kind, self.order = kind, order
+        self.kind, self.order, self.pull = kind, order, pull
         self._mask = None
         if mask is not None:
-            self._mask = np.ascontiguousarray(mask, dtype=np.int8)
+            self._mask = np.ascontiguousarray(np.asarray(mask, dtype=np.int8).reshape(-1, order="F"))
             grid.mask = self._mask.ctypes.data_as(K.c_int8_p)
-        self.Nx, self.Ny = grid.Nx, grid.Ny
-        self.N = self.Nx * self.Ny
+        if grid.j_end <= grid.j_begin:
+            grid.j_begin, grid.j_end = 0, grid.Ny
+        self.Nx = grid.Nx
+        self.j_begin, self.j_end = grid.j_begin, grid.j_end
+        self.Ny = self.ny_loc = grid.j_end - grid.j_begin     # rows owned by this model
+        self.N = self.Nx * self.ny_loc
+        self._halo_rows = halo_rows
         h = C.c_void_p()
         rc = self.L.picles_oracle_create(C.byref(grid), C.byref(phys), C.byref(ode), C.byref(model), order, C.byref(h))
         if rc != 0:
             raise RuntimeError(f"picles_oracle_create rc={rc}")
         self.h = h
         self.L.picles_oracle_set_threads(h, threads)
+        if halo_rows != 1:
+            self.L.picles_oracle_set_halo_rows(h, halo_rows)
 
     def close(self):
         if self.h:
@@ -129,10 +144,51 @@ class OracleModel:
         self.L.picles_oracle_seed(self.h, t0)
 
     def time_step(self, dt, flags=0):
-        self.L.picles_oracle_time_step(self.h, dt, flags)
+        if self.pull:
+            rc = self.L.picles_oracle_time_step_pull(self.h, dt, flags)
+        else:
+            rc = self.L.picles_oracle_time_step(self.h, dt, flags)
+        assert rc == 0, rc
+
+    # --- slab phases (same names as picles_amd.driver.HipModel) ---
+    def begin_step(self, dt, flags=0):
+        self.L.picles_oracle_begin_step(self.h, dt, flags)
+
+    def advance_rows(self, which, stream=None):
+        rc = self.L.picles_oracle_advance_rows(self.h, which)
+        assert rc == 0, rc
+
+    def scatter_remesh(self, stream=None):
+        rc = self.L.picles_oracle_scatter_rows(self.h, 1)
+        assert rc == 0, rc
+
+    def _halo(self, side, send):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.L.picles_oracle_halo_ptr(self.h, side, send, C.byref(p), C.byref(n))
+        return p.value, n.value
+
+    def halo_send(self, side):
+        return self._halo(side, 1)
+
+    def halo_recv(self, side):
+        return self._halo(side, 0)
+
+    @property
+    def halo_rows(self):
+        return self.L.picles_oracle_halo_rows(self.h)
+
+    def set_halo_rows(self, r):
+        self.L.picles_oracle_set_halo_rows(self.h, r)
+
+    def sync(self):
+        pass
+
+    def reset_counters(self):
+        pass
 
     def advance(self, dt, flags=0):
-        self.L.picles_oracle_advance(self.h, dt)
+        rc = self.L.picles_oracle_advance(self.h, dt)
+        assert rc == 0, rc
 
     def remesh(self, dt):
         self.L.picles_oracle_remesh(self.h, dt)

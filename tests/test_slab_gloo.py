@@ -1,0 +1,92 @@
+"""N>1 path on CPU: the slab-partitioned step of picles_amd.parallel (edge rows -> halo exchange of
+scatter records -> interior rows -> pull-scatter + remesh) run by 2 and 3 gloo ranks must equal the
+single-domain step bit for bit.  The compute backend here is the CPU oracle's slab implementation
+(same C-ABI phase names); on the GPU box test_gpu_slabs.py runs the same driver over the HIP library."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _cfg(name):
+    from picles_amd import configs
+    if name == "periodic":
+        return configs.bench06_box(n=24, dx=1500.0)
+    if name == "nonperiodic_generic":
+        return configs.T04_2D_reg_test(U10=10.0, V10=3.0, periodic=False, n=25, L=96e3)
+    if name == "periodic_model_ring":
+        return configs.T04_2D_reg_test(U10=-10.0, V10=10.0, periodic=True, n=25, L=96e3)
+    if name == "calm":
+        return configs.growing_decaying_winds(n=24)
+    raise KeyError(name)
+
+
+def _worker(rank, world, port, name, n_steps, halo, outdir):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import _oracle as O
+    from picles_amd.parallel import SlabModel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+    def fac(g, p, o, m, mask, halo_rows=1):
+        return O.OracleModel(g, p, o, m, kind="pmath", order=1, threads=1, mask=mask, halo_rows=halo_rows)
+
+    cfg = _cfg(name)
+    model = SlabModel(cfg.model, rank, world, halo_rows=halo, backend_factory=fac)
+    model.seed()
+    for _ in range(n_steps):
+        model.time_step(cfg.Δt)
+    S = model.gather_state()
+    ov = model.backend.get_counters()["halo_overflow"]
+    if rank == 0:
+        np.save(os.path.join(outdir, "state.npy"), S)
+    assert ov == 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single(name, n_steps):
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _oracle as O
+    from picles_amd.parallel import SlabModel
+
+    def fac(g, p, o, m, mask, halo_rows=1):
+        return O.OracleModel(g, p, o, m, kind="pmath", order=1, threads=2, mask=mask)   # sequential push
+    cfg = _cfg(name)
+    m = SlabModel(cfg.model, 0, 1, backend_factory=fac)
+    m.seed()
+    for _ in range(n_steps):
+        m.time_step(cfg.Δt)
+    return m.get_state()
+
+
+@pytest.mark.parametrize("name,world,halo", [("periodic", 2, 1), ("periodic", 3, 2), ("nonperiodic_generic", 2, 1),
+                                             ("periodic_model_ring", 3, 1), ("calm", 2, 2)])
+def test_slabs_equal_single_domain(tmp_path, name, world, halo):
+    n_steps = 4
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, name, n_steps, halo, str(tmp_path)), nprocs=world, join=True)
+    S = np.load(tmp_path / "state.npy")
+    ref = _single(name, n_steps)
+    assert S.shape == ref.shape
+    assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
+
+
+def test_slab_rows_partition():
+    from picles_amd.parallel import slab_rows
+    for Ny, w in ((4096, 8), (51, 4), (7, 3)):
+        rows = [slab_rows(Ny, w, r) for r in range(w)]
+        assert rows[0][0] == 0 and rows[-1][1] == Ny
+        assert all(rows[k][1] == rows[k + 1][0] for k in range(w - 1))
+        assert max(b - a for a, b in rows) - min(b - a for a, b in rows) <= 1
