@@ -87,6 +87,8 @@ class HaloExchange:
             return []
         dist = self.dist
         if self.staged:
+            if not self.host_blocks:
+                self.torch.cuda.current_stream().synchronize()   # edge kernel done before the D2H copies
             for k in ("send_lo", "send_hi"):
                 p, n = self.blocks[k]
                 rc = self._copy(self.host[k].data_ptr(), p, n, 2)  # D2H

@@ -1,0 +1,217 @@
+"""More GPU parity cases through the C ABI: branches (off/on, NaN guard, clamp), masks and mixed
+periodicity with reach > 1, the split advance/remesh API, user-set particles (propagation-only
+blob of tests/T03_PIC_propagation_2d_blob.jl), the atomic LDS-tile push and the generic
+particle-list scatter.  Deterministic paths are compared BITWISE with the CPU oracle."""
+import numpy as np
+import pytest
+
+from picles_amd import configs, _capi as K
+from picles_amd.grids import TwoDCartesianGridMesh
+from picles_amd.simulations import Simulation, initialize_simulation
+from picles_amd.timesteppers import time_step, time_step_advance, time_step_remesh
+from helpers import make_model, run_states, assert_bitwise
+
+pytestmark = pytest.mark.gpu
+ORACLE = ("pmath", 1)
+
+
+def _pair(cfg_fn):
+    return make_model(cfg_fn(), "hip"), make_model(cfg_fn(), ORACLE)
+
+
+def _init(m, dt):
+    initialize_simulation(Simulation(m, Δt=dt, stop_time=1.0))
+
+
+def _same_particles(g, o):
+    zg, ong, _, stg = g.backend.get_particles()
+    zo, ono, _, sto = o.backend.get_particles()
+    assert_bitwise(ong, ono, "on")
+    assert_bitwise(stg, sto, "status")
+    stepped = (sto & 1) == 1
+    for c in range(5):
+        assert_bitwise(zg[..., c][stepped], zo[..., c][stepped], f"z[{c}]")
+
+
+def test_calm_region_time_varying_winds_bitwise():
+    fn = lambda: configs.growing_decaying_winds(n=40, n_steps=8)
+    g, o = _pair(fn)
+    cfg = fn()
+    for m in (g, o):
+        _init(m, cfg.Δt)
+    for k in range(8):
+        for m in (g, o):
+            time_step(m, cfg.Δt, zero_first=True)
+        assert_bitwise(g.State, o.State, f"State step {k}")
+    _same_particles(g, o)
+    cg, co = g.backend.get_counters(), o.backend.get_counters()
+    assert cg["reseeds"] == co["reseeds"] and cg["particles_advanced"] == co["particles_advanced"]
+    assert cg["max_reach"] == co["max_reach"] >= 1
+
+
+def _masked_cfg():
+    cfg = configs.bench06_box(n=32, dx=1000.0)
+    cfg.Δt = 1200.0
+    mask = np.ones((32, 32), dtype=bool)
+    mask[12:17, 9:20] = False
+    g = cfg.model["grid"]
+    cfg.model["grid"] = TwoDCartesianGridMesh(0.0, g.stats.xmax, 32, 0.0, g.stats.ymax, 32, mask=mask,
+                                              periodic_boundary=(True, False))
+    return cfg
+
+
+def test_land_mask_mixed_periodicity_large_reach_bitwise():
+    g, o = _pair(_masked_cfg)
+    for m in (g, o):
+        _init(m, 1200.0)
+    for k in range(12):
+        for m in (g, o):
+            time_step(m, 1200.0, zero_first=True)
+        assert_bitwise(g.State, o.State, f"State step {k}")
+    assert g.backend.get_counters()["max_reach"] >= 2
+    _same_particles(g, o)
+
+
+def test_split_advance_remesh_bitwise():
+    fn = lambda: configs.example_00_minimal(n=25, L=48e3)
+    g, o = _pair(fn)
+    for m in (g, o):
+        _init(m, 600.0)
+    for k in range(3):
+        for m in (g, o):
+            m.backend.zero_state()
+            time_step_advance(m, 600.0)
+        assert_bitwise(g.State, o.State, f"after advance {k}")
+        for m in (g, o):
+            time_step_remesh(m, 600.0)
+            m.backend.tick(600.0); m.clock.time += 600.0
+    _same_particles(g, o)
+
+
+def test_user_particles_propagation_only_blob():
+    def fn():
+        cfg = configs.bench06_box(n=24, dx=1000.0)
+        s = cfg.model["ODEsys"]
+        s.input = s.dissipation = s.peak_shift = s.direction = False
+        return cfg
+    g, o = _pair(fn)
+    z = np.zeros((24, 24, 5)); z[..., 0] = -3.0; z[..., 1] = 1.0
+    on = np.zeros((24, 24), dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    for (i, j) in [(5, 5), (6, 5), (5, 6), (22, 23), (23, 23), (0, 0)]:
+        on[i, j] = 1
+        z[i, j, :3] = [rng.uniform(-3, 0), rng.uniform(-2.5, 2.5), rng.uniform(-2.5, 2.5)]
+    for m in (g, o):
+        m.backend.set_winds(np.zeros((24, 24)), np.zeros((24, 24)))
+        m.backend.set_particles(z, on)
+        m.backend.zero_state()
+        m.backend.advance(600.0)
+    Sg, So = g.backend.get_state(), o.backend.get_state()
+    assert_bitwise(Sg, So, "blob State")
+    assert Sg[..., 0].sum() == pytest.approx(np.exp(z[..., 0])[on == 1].sum(), rel=1e-13)   # conservation
+
+
+def test_nan_and_clamp_guards():
+    fn = lambda: configs.example_00_minimal(n=17, L=32e3)
+    g, o = _pair(fn)
+    for m in (g, o):
+        _init(m, 600.0)
+    zg, on, _, _ = g.backend.get_particles()
+    z = zg.copy()
+    z[5, 5, 0] = np.nan            # NaN guard -> re-seed from the wind (mapping_2D.jl:196-211)
+    z[6, 6, 1] = np.inf            # Inf guard (:213-222)
+    z[7, 7, 0] = 5.0               # > log(17): clamp (:224-235)
+    for m in (g, o):
+        m.backend.set_particles(z, on)
+        m.backend.zero_state()
+        time_step(m, 600.0)
+    assert_bitwise(g.State, o.State, "State")
+    _, _, _, st = g.backend.get_particles()
+    assert st[5, 5] & K.ST_RESEED_NAN and st[6, 6] & (K.ST_RESEED_INF | K.ST_RESEED_NAN) and st[7, 7] & K.ST_CLAMPED
+    _same_particles(g, o)
+    assert g.backend.get_counters()["clamps"] == o.backend.get_counters()["clamps"] >= 1
+
+
+@pytest.mark.parametrize("cfg_fn", [lambda: configs.bench06_box(n=96), lambda: configs.example_00_minimal(n=70, L=138e3),
+                                    _masked_cfg])
+def test_atomic_push_matches_pull(cfg_fn):
+    """PICLES_STEP_ATOMIC: LDS-tile push with fp64 atomics; sum order differs => 1e-13 relative"""
+    a, b = make_model(cfg_fn(), "hip"), make_model(cfg_fn(), "hip")
+    dt = cfg_fn().Δt
+    for m in (a, b):
+        _init(m, dt)
+    for k in range(4):
+        a.backend.time_step(dt, K.STEP_ZERO_FIRST)
+        b.backend.time_step(dt, K.STEP_ZERO_FIRST | K.STEP_ATOMIC)
+        Sa, Sb = a.backend.get_state(), b.backend.get_state()
+        scale = np.abs(Sa).max(axis=(0, 1), keepdims=True)
+        assert np.all(np.abs(Sa - Sb) <= 1e-13 * scale), (k, np.abs(Sa - Sb).max())
+
+
+def _numpy_push(Nx, Ny, px, py, ij, xy, ch):
+    S = np.zeros((Nx, Ny, 3))
+    for (i, j), (x, y), c in zip(ij, xy, ch):
+        bx, by = int(np.floor(x)), int(np.floor(y))
+        wx1 = np.rint((x - bx) * 1e6) / 1e6
+        wy1 = np.rint((y - by) * 1e6) / 1e6
+        for ax, ay in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            ii, jj = i + bx + ax, j + by + ay
+            if not px and not (0 <= ii < Nx):
+                continue
+            if not py and not (0 <= jj < Ny):
+                continue
+            w = (wx1 if ax else 1 - wx1) * (wy1 if ay else 1 - wy1)
+            S[ii % Nx, jj % Ny] += w * np.asarray(c)
+    return S
+
+
+@pytest.mark.parametrize("periodic", [(True, True), (False, False), (True, False)])
+def test_generic_particle_list_scatter(periodic):
+    """picles_scatter_particles: cell list + LDS tiles, micro-benchmark inputs of SURVEY §8d
+    (offsets U(-0.9,0.9) cells plus a few far ones, PCG64 seed 12345)"""
+    cfg = configs.bench06_box(n=100, dx=1000.0)
+    g = cfg.model["grid"]
+    cfg.model["grid"] = TwoDCartesianGridMesh(g.stats.xmax, 100, g.stats.ymax, 100, periodic_boundary=periodic)
+    m = make_model(cfg, "hip")
+    rng = np.random.Generator(np.random.PCG64(12345))
+    n = 20000
+    ij = np.stack([rng.integers(0, 100, n), rng.integers(0, 100, n)], axis=1)
+    xy = rng.uniform(-0.9, 0.9, (n, 2))
+    xy[:50] *= 4.0                                # beyond the LDS apron: direct global atomics
+    ch = np.stack([rng.uniform(1e-4, 1, n), rng.uniform(-1e-2, 1e-2, n), rng.uniform(-1e-2, 1e-2, n)], axis=1)
+    m.backend.zero_state()
+    m.backend.scatter_particles(ij, xy, ch)
+    S = m.backend.get_state()
+    ref = _numpy_push(100, 100, periodic[0], periodic[1], ij, xy, ch)
+    assert np.abs(S - ref).max() <= 1e-12 * np.abs(ref).max()
+    m.backend.scatter_particles(np.zeros((0, 2), dtype=int), np.zeros((0, 2)), np.zeros((0, 3)))   # empty input is a no-op
+    assert np.array_equal(m.backend.get_state(), S)
+
+
+def test_full_size_4096_properties():
+    """BASELINE size (4096², 1 particle/cell, periodic): the oracle would take minutes, so check
+    size-independent properties: a homogeneous periodic box stays uniform, every node follows the
+    single-particle oracle trajectory, and deterministic reruns are bitwise identical."""
+    import _oracle as O
+    cfg = configs.box4096(n_steps=3)
+    m = make_model(cfg, "hip")
+    _init(m, cfg.Δt)
+    for _ in range(3):
+        m.backend.time_step(cfg.Δt, K.STEP_ZERO_FIRST)
+    S = m.backend.get_state()
+    e = S[..., 0]
+    assert np.abs(e / e[0, 0] - 1).max() < 1e-12
+    # single-particle reference: a 12x12 periodic box through the oracle
+    small = make_model(configs.bench06_box(n=12), ORACLE)
+    _init(small, cfg.Δt)
+    for _ in range(3):
+        small.backend.time_step(cfg.Δt, K.STEP_ZERO_FIRST)
+    Ss = small.backend.get_state()
+    assert np.abs(e[2000:2010, 2000:2010] / Ss[5, 5, 0] - 1).max() < 1e-12
+    c = m.backend.get_counters()
+    assert c["particles_advanced"] == 3 * 4096 * 4096 and c["halo_overflow"] == 0
+    m2 = make_model(configs.box4096(n_steps=3), "hip")
+    _init(m2, cfg.Δt)
+    for _ in range(3):
+        m2.backend.time_step(cfg.Δt, K.STEP_ZERO_FIRST)
+    assert np.array_equal(m2.backend.get_state(), S)
