@@ -518,6 +518,7 @@ struct picles_ctx {
     hipStream_t stream;
     hipEvent_t ev_edge;
     bool edge_pending = false;
+    bool step_fresh = false;
     signed char *d_mask = nullptr;
     std::vector<signed char> h_mask;
     double clock = 0.0;
@@ -741,7 +742,7 @@ PX_EXPORT int32_t picles_sync(picles_ctx *c)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());
     return 0;
 }
 
@@ -752,6 +753,7 @@ PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double
 {
     if (!c || !u0 || !v0) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());   /* the previous step may still read the wind planes */
     size_t b = (size_t)c->A.n * 8;
     HIPCHK(c, hipMemcpyAsync(c->A.u0, u0, b, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->A.v0, v0, b, hipMemcpyHostToDevice, c->stream));
@@ -809,9 +811,7 @@ PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
     c->step_dt = dt;
     c->step_flags = flags;
     c->edge_pending = false;
-    HIPCHK(c, hipSetDevice(c->device));
-    /* max_reach / overflow are per-advance quantities */
-    HIPCHK(c, hipMemsetAsync(&c->A.cnt->max_reach, 0, sizeof(int), c->stream));
+    c->step_fresh = true;   /* the first advance_rows of the step clears max_reach on ITS stream */
     return 0;
 }
 
@@ -834,6 +834,10 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     } else return fail(c, -2, "bad row selector");
     long long nt = (long long)(n0 + n1) * G.Nx;
     if (nt == 0) return 0;
+    if (c->step_fresh) {   /* max_reach is a per-step quantity */
+        HIPCHK(c, hipMemsetAsync(&c->A.cnt->max_reach, 0, sizeof(int), s));
+        c->step_fresh = false;
+    }
     timing_begin(c, s, 0);
     {
         const KParams &P = c->P;
@@ -942,6 +946,7 @@ PX_EXPORT int32_t picles_remesh(picles_ctx *c, double dt)
 static int d2h(picles_ctx *c, void *dst, const void *src, size_t bytes)
 {
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());   /* kernels may have run on caller-provided streams */
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -949,6 +954,7 @@ static int d2h(picles_ctx *c, void *dst, const void *src, size_t bytes)
 static int h2d(picles_ctx *c, void *dst, const void *src, size_t bytes)
 {
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;

@@ -182,6 +182,7 @@ class SlabModel:
         self._wind_window = None
         self.upload_winds(0.0, self.timestep)
         self.backend.seed(0.0)
+        self.backend.sync()        # the seed kernel runs on the context stream, the steps on s_edge / s_main
         self.clock = 0.0
 
     def time_step(self, dt, flags=K.STEP_ZERO_FIRST):
@@ -192,6 +193,9 @@ class SlabModel:
         elif self.use_streams:
             torch = self.ex.torch
             b.begin_step(dt, flags)
+            # the previous step's scatter+remesh (stream M) wrote the particles and read the records
+            # that the edge advance is about to read / overwrite
+            self.s_edge.wait_stream(self.s_main)
             with torch.cuda.stream(self.s_edge):
                 b.advance_rows(K.ROWS_EDGE, self.s_edge.cuda_stream)
                 works = self.ex.start()            # RCCL send/recv ordered after the edge kernel
