@@ -157,7 +157,9 @@ def test_energy_clamp_guard():
 @pytest.mark.parametrize("cfg_fn", [lambda: configs.bench06_box(n=96), lambda: configs.example_00_minimal(n=70, L=138e3),
                                     _masked_cfg])
 def test_atomic_push_matches_pull(cfg_fn):
-    """PICLES_STEP_ATOMIC: LDS-tile push with fp64 atomics; sum order differs => 1e-13 relative"""
+    """PICLES_STEP_ATOMIC: LDS-tile push with fp64 atomics.  The sum order differs from the pull
+    (last-bit differences per step) and the difference feeds back through remesh + the adaptive
+    ODE: 1e-14 after one step, bounded by 1e-10 relative over four."""
     a, b = make_model(cfg_fn(), "hip"), make_model(cfg_fn(), "hip")
     dt = cfg_fn().Δt
     for m in (a, b):
@@ -167,7 +169,8 @@ def test_atomic_push_matches_pull(cfg_fn):
         b.backend.time_step(dt, K.STEP_ZERO_FIRST | K.STEP_ATOMIC)
         Sa, Sb = a.backend.get_state(), b.backend.get_state()
         scale = np.abs(Sa).max(axis=(0, 1), keepdims=True)
-        assert np.all(np.abs(Sa - Sb) <= 1e-13 * scale), (k, np.abs(Sa - Sb).max())
+        tol = 1e-14 if k == 0 else 1e-10
+        assert np.all(np.abs(Sa - Sb) <= tol * scale), (k, np.abs(Sa - Sb).max())
 
 
 def _numpy_push(Nx, Ny, px, py, ij, xy, ch):
