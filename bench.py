@@ -23,7 +23,7 @@ sys.path.insert(0, str(ROOT))
 B_ALG = 64.0          # algorithmic HBM bytes per particle-step (SURVEY §8d / DESIGN.md)
 HBM_PEAK_GBPS = 8000.0
 FP64_PEAK_TFLOPS = 78.6
-FLOP_PER_RHS = 260.0  # fp64 operations of one kernel-order RHS incl. expanded div/sqrt/exp
+FLOP_PER_RHS = 240.0  # executed fp64 flops per RHS evaluation, all-in (2*FMA + MUL + ADD of the RK loop / 6)
 
 
 def cpu_baseline(args, W, K):

@@ -84,6 +84,7 @@ static const double E1 = -71.0 / 57600.0, E3 = 71.0 / 16695.0, E4 = -71.0 / 1920
 #define CTRL_QMIN 0.2
 #define CTRL_QMAX 10.0
 #define CTRL_QOLDINIT 1e-4
+#define CTRL_LNQOLDINIT (-9.210340371976182) /* ln(1e-4); order 1 carries ln(qold) */
 
 typedef struct po_consts {
     double p, n, e_T, inv_eT, inv_rg, inv_dx, inv_dy;
@@ -509,6 +510,29 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
         int last = !(dt < rem);
         double EEst = po_dp5_try(M, idx, z, k1, t_start + tr, h, unew, k7, st);
         if (!(EEst == EEst)) { EEst = INFINITY; st->status |= PICLES_ST_NONFINITE; }
+        int accept = (EEst <= 1.0) || (od->force_dtmin && h <= od->dtmin);
+        if (M->order == 1) {
+            /* kernel order: PI controller in log space, *qold holds ln(qold) */
+            double le = o_log(EEst);
+            if (accept) {
+                st->acc++;
+                double qi = o_exp(PO_FMA(CTRL_BETA2, *qold, -(CTRL_BETA1 * le))) * CTRL_GAMMA;
+                qi = (qi > CTRL_QMAX) ? CTRL_QMAX : qi;
+                qi = (qi < CTRL_QMIN) ? CTRL_QMIN : qi;
+                *qold = (le > CTRL_LNQOLDINIT) ? le : CTRL_LNQOLDINIT;
+                dt = h * qi;
+                for (int i = 0; i < 5; i++) { z[i] = unew[i]; k1[i] = k7[i]; }
+                tr = last ? DT : tr + h;
+                if (z[0] != z[0] || z[1] != z[1] || z[2] != z[2] || z[3] != z[3] || z[4] != z[4]) break;
+            } else {
+                st->rej++;
+                double r = CTRL_GAMMA * o_exp(-(CTRL_BETA1 * le));
+                r = (r < CTRL_QMIN) ? CTRL_QMIN : r;
+                dt = h * r;
+                if (!od->force_dtmin && h <= od->dtmin) { st->status |= PICLES_ST_DTMIN; break; }
+            }
+            continue;
+        }
         /* stepsize_controller!(PIController) */
         double q11 = 0.0, q;
         if (EEst == 0.0) {
@@ -521,7 +545,6 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
             q = (qg < hi) ? qg : hi;
             q = (q > lo) ? q : lo;
         }
-        int accept = (EEst <= 1.0) || (od->force_dtmin && h <= od->dtmin);
         if (accept) {
             st->acc++;
             *qold = (EEst > CTRL_QOLDINIT) ? EEst : CTRL_QOLDINIT; /* step_accept_controller! */
@@ -656,7 +679,7 @@ static void po_remesh_particle(po_model *M, int64_t idx, double DT)
     } else if (u * u + v * v >= M->od.wind_min_squared) {                   /* B :328-336, C :338-344 */
         po_reseed(M, u, v, DT, z);
         for (int k = 0; k < 5; k++) M->z[idx + k * M->N] = z[k];
-        M->qold[idx] = CTRL_QOLDINIT;              /* reinit! resets the controller */
+        M->qold[idx] = M->order ? CTRL_LNQOLDINIT : CTRL_QOLDINIT;   /* reinit! resets the controller */
         M->dtn[idx] = -1.0;
         M->on[idx] = 1;
         __atomic_fetch_add(&M->cnt.reseeds, 1, __ATOMIC_RELAXED);
@@ -773,7 +796,7 @@ PO_EXPORT int32_t picles_oracle_seed(po_model *M, double t0)
     memset(&M->cnt, 0, sizeof(M->cnt));
     for (int64_t n = 0; n < N; n++) {
         M->status[n] = 0;
-        M->qold[n] = CTRL_QOLDINIT;
+        M->qold[n] = M->order ? CTRL_LNQOLDINIT : CTRL_QOLDINIT;
         M->dtn[n] = M->od.dt0;
         for (int c = 0; c < 5; c++) M->z[n + c * N] = 0.0;
         M->on[n] = 0;

@@ -84,6 +84,7 @@ struct KParams {
 #define PI_QMIN 0.2
 #define PI_QMAX 10.0
 #define PI_QOLDINIT 1e-4
+#define PI_LNQOLDINIT (-9.210340371976182) /* ln(1e-4): the carried controller memory is ln(qold) */
 
 struct Vec5 {
     double lne, cx, cy, x, y;
@@ -318,7 +319,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
  * Only the stage derivatives of (lne, c̄x, c̄y) are kept; the x,y rows of the tableau are
  * accumulated as the stages appear (same fma order as the full Butcher sums). */
 template <bool FAST, bool STATIC>
-PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &qold, double &dtn,
+PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, double &dtn,
                          double t_start, double DT, PStats &st)
 {
     const double ipx = (FAST || P.propagation) ? P.inv_dx : 0.0;
@@ -401,31 +402,26 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &qold,
 #undef ST7
 #undef ERRC
         if (!(EEst == EEst)) { EEst = pm_inf(); st.status |= 128 /*PICLES_ST_NONFINITE*/; }
-        double q11 = 0.0, q;
-        if (EEst == 0.0) {
-            q = 1.0 / PI_QMAX;
-        } else {
-            q11 = pm_pow(EEst, PI_BETA1);
-            q = q11 / pm_pow(qold, PI_BETA2);
-            double qg = q / PI_GAMMA;
-            const double lo = 1.0 / PI_QMAX, hi = 1.0 / PI_QMIN;
-            q = (qg < hi) ? qg : hi;
-            q = (q > lo) ? q : lo;
-        }
+        /* PI controller in log space (kernel order): 1/q = γ·qold^β2 / EEst^β1, clamped to
+         * [qmin, qmax]; lq = ln(qold) is the carried controller memory. One log + one exp per step. */
+        double le = pm_log(EEst);
         bool accept = (EEst <= 1.0) || (P.force_dtmin && h <= P.dtmin);
         if (accept) {
             st.acc++;
-            qold = (EEst > PI_QOLDINIT) ? EEst : PI_QOLDINIT;
-            dt = h / q;
+            double qi = pm_exp(PM_FMA(PI_BETA2, lq, -(PI_BETA1 * le))) * PI_GAMMA;
+            qi = (qi > PI_QMAX) ? PI_QMAX : qi;
+            qi = (qi < PI_QMIN) ? PI_QMIN : qi;
+            lq = (le > PI_LNQOLDINIT) ? le : PI_LNQOLDINIT;
+            dt = h * qi;
             z = un;
             k1 = k7;
             tr = last ? DT : tr + h;
             if (z.lne != z.lne || z.cx != z.cx || z.cy != z.cy || z.x != z.x || z.y != z.y) break;
         } else {
             st.rej++;
-            double f = q11 / PI_GAMMA;
-            const double hi = 1.0 / PI_QMIN;
-            dt = h / ((f < hi) ? f : hi);
+            double r = PI_GAMMA * pm_exp(-(PI_BETA1 * le));
+            r = (r < PI_QMIN) ? PI_QMIN : r;
+            dt = h * r;
             if (!P.force_dtmin && h <= P.dtmin) { st.status |= 64 /*PICLES_ST_DTMIN*/; break; }
         }
     }

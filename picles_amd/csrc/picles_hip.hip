@@ -9,7 +9,7 @@
  *   state[3][n]      e, m_x, m_y planes              (reference State[Nx,Ny,3], col-major)
  *   movie[3][n]      MovieState snapshot
  *   z[5][n]          lne, c̄x, c̄y, x, y planes        (ParticleInstance2D.ODEIntegrator.u)
- *   qold[n], dtn[n]  PI-controller memory, next dt (<0 => auto_dt_reset!)
+ *   qold[n], dtn[n]  PI-controller memory ln(qold), next dt (<0 => auto_dt_reset!)
  *   on[n] u8, pflags[n] u8 (bit0 stepped, bit1 group-2 (mask 3), bit2 boundary), status[n] i32
  *   wind u0,v0,u1,v1 [n]
  *   rec[(ny_loc+2R)][6][Nx]   per-row scatter records e, m_x, m_y, x, y, flag of every particle
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, cons
     }
     A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
     A.on[t] = (unsigned char)on;
-    A.qold[t] = PI_QOLDINIT;
+    A.qold[t] = PI_LNQOLDINIT;
     A.dtn[t] = P.dt0;
     A.status[t] = 0;
     A.state[t] = e; A.state[t + A.n] = mx; A.state[t + 2 * A.n] = my;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &
     } else if (u * u + v * v >= P.wind_min_sq) {                               /* B, C */
         reseed(P, u, v, DT, z);
         A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
-        A.qold[t] = PI_QOLDINIT;   /* reinit! */
+        A.qold[t] = PI_LNQOLDINIT;   /* reinit! */
         A.dtn[t] = -1.0;
         A.on[t] = 1;
         reseeds = 1;

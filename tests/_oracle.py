@@ -262,7 +262,9 @@ class OracleModel:
         self.L.picles_oracle_rhs(self.h, K.dptr(z), u, v, K.dptr(dz))
         return dz
 
-    def integrate(self, idx, z, t_start, DT, qold=1e-4, dtn=-1.0):
+    def integrate(self, idx, z, t_start, DT, qold=None, dtn=-1.0):
+        if qold is None:   # controller memory: qold (order 0) or ln(qold) (order 1)
+            qold = -9.210340371976182 if self.order == 1 else 1e-4
         z = np.array(z, dtype=np.float64)
         q = np.array([qold])
         d = np.array([dtn])
