@@ -86,6 +86,48 @@ struct KParams {
 #define PI_QOLDINIT 1e-4
 #define PI_LNQOLDINIT (-9.210340371976182) /* ln(1e-4): the carried controller memory is ln(qold) */
 
+/* The 29 tableau constants as one object.  On the device they are read once per thread from
+ * LDS into VGPRs before the RK loop: as 64-bit literals they would need 58 SGPRs, overflow the
+ * scalar file and be spilled to VGPR lanes (v_readlane/v_writelane = VALU slots in the hot loop). */
+struct DPTab {
+    double a21, a31, a32, a41, a42, a43, a51, a52, a53, a54, a61, a62, a63, a64, a65;
+    double a71, a73, a74, a75, a76, c2, c3, c4, c5, e1, e3, e4, e5, e6, e7;
+};
+#define DPTAB_INIT                                                                                   \
+    {DP_A21, DP_A31, DP_A32, DP_A41, DP_A42, DP_A43, DP_A51, DP_A52, DP_A53, DP_A54, DP_A61, DP_A62,  \
+     DP_A63, DP_A64, DP_A65, DP_A71, DP_A73, DP_A74, DP_A75, DP_A76, DP_C2, DP_C3, DP_C4, DP_C5,      \
+     DP_E1, DP_E3, DP_E4, DP_E5, DP_E6, DP_E7}
+#define DPTAB_N 30
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ const double DPTAB_C[DPTAB_N] = DPTAB_INIT;
+__device__ __forceinline__ double *dp_lds_tab(void)
+{
+    __shared__ double tab[32];
+    return tab;
+}
+__device__ __forceinline__ void dp_device_init(void)   /* call before pm_device_init (shares its barrier) */
+{
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + DPTAB_N) dp_lds_tab()[threadIdx.x - 32] = DPTAB_C[threadIdx.x - 32];
+}
+__device__ __forceinline__ void dp_load(DPTab &T)
+{
+    const double *t = dp_lds_tab();
+    double *o = &T.a21;
+#pragma unroll
+    for (int k = 0; k < DPTAB_N; k++) o[k] = t[k];
+}
+#else
+#if defined(__HIPCC__)
+__device__ __forceinline__ void dp_device_init(void) {}
+#endif
+PM_HD void dp_load(DPTab &T)
+{
+    const DPTab c = DPTAB_INIT;
+    T = c;
+}
+#endif
+
 struct Vec5 {
     double lne, cx, cy, x, y;
 };
@@ -326,6 +368,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     const double ipy = (FAST || P.propagation) ? P.inv_dy : 0.0;
     Vec3 k1, k2, k3, k4, k5, k6, k7;
     WindD W;
+    DPTab T;
+    dp_load(T);
     double tr = 0.0;
     if (STATIC) wind_derive(w.u0, w.v0, W);
     else wind_stage<false>(P, w, t_start, W);
@@ -346,51 +390,51 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         double kx, ky;          /* stage x,y tendencies */
         double ax, ay, ex, ey;  /* running Σ a7i k_i and Σ e_i k_i of the x,y components */
         kx = z.cx * ipx; ky = z.cy * ipy;
-        ax = DP_A71 * kx; ay = DP_A71 * ky;
-        ex = DP_E1 * kx; ey = DP_E1 * ky;
+        ax = T.a71 * kx; ay = T.a71 * ky;
+        ex = T.e1 * kx; ey = T.e1 * ky;
         {
-            double a21h = h * DP_A21;
+            double a21h = h * T.a21;
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
         }
-        wind_stage<STATIC>(P, w, PM_FMA(DP_C2, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(T.c2, h, t), W);
         rhs3<FAST>(P, gl, gx, gy, W, k2);
-#define ST3(c) PM_FMA(h, PM_FMA(DP_A32, k2.c, DP_A31 * k1.c), z.c)
+#define ST3(c) PM_FMA(h, PM_FMA(T.a32, k2.c, T.a31 * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(DP_C3, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(T.c3, h, t), W);
         rhs3<FAST>(P, gl, gx, gy, W, k3);
         kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(DP_A73, kx, ax); ay = PM_FMA(DP_A73, ky, ay);
-        ex = PM_FMA(DP_E3, kx, ex); ey = PM_FMA(DP_E3, ky, ey);
-#define ST4(c) PM_FMA(h, PM_FMA(DP_A43, k3.c, PM_FMA(DP_A42, k2.c, DP_A41 * k1.c)), z.c)
+        ax = PM_FMA(T.a73, kx, ax); ay = PM_FMA(T.a73, ky, ay);
+        ex = PM_FMA(T.e3, kx, ex); ey = PM_FMA(T.e3, ky, ey);
+#define ST4(c) PM_FMA(h, PM_FMA(T.a43, k3.c, PM_FMA(T.a42, k2.c, T.a41 * k1.c)), z.c)
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(DP_C4, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(T.c4, h, t), W);
         rhs3<FAST>(P, gl, gx, gy, W, k4);
         kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(DP_A74, kx, ax); ay = PM_FMA(DP_A74, ky, ay);
-        ex = PM_FMA(DP_E4, kx, ex); ey = PM_FMA(DP_E4, ky, ey);
-#define ST5(c) PM_FMA(h, PM_FMA(DP_A54, k4.c, PM_FMA(DP_A53, k3.c, PM_FMA(DP_A52, k2.c, DP_A51 * k1.c))), z.c)
+        ax = PM_FMA(T.a74, kx, ax); ay = PM_FMA(T.a74, ky, ay);
+        ex = PM_FMA(T.e4, kx, ex); ey = PM_FMA(T.e4, ky, ey);
+#define ST5(c) PM_FMA(h, PM_FMA(T.a54, k4.c, PM_FMA(T.a53, k3.c, PM_FMA(T.a52, k2.c, T.a51 * k1.c))), z.c)
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(DP_C5, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(T.c5, h, t), W);
         rhs3<FAST>(P, gl, gx, gy, W, k5);
         kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(DP_A75, kx, ax); ay = PM_FMA(DP_A75, ky, ay);
-        ex = PM_FMA(DP_E5, kx, ex); ey = PM_FMA(DP_E5, ky, ey);
-#define ST6(c) PM_FMA(h, PM_FMA(DP_A65, k5.c, PM_FMA(DP_A64, k4.c, PM_FMA(DP_A63, k3.c, PM_FMA(DP_A62, k2.c, DP_A61 * k1.c)))), z.c)
+        ax = PM_FMA(T.a75, kx, ax); ay = PM_FMA(T.a75, ky, ay);
+        ex = PM_FMA(T.e5, kx, ex); ey = PM_FMA(T.e5, ky, ey);
+#define ST6(c) PM_FMA(h, PM_FMA(T.a65, k5.c, PM_FMA(T.a64, k4.c, PM_FMA(T.a63, k3.c, PM_FMA(T.a62, k2.c, T.a61 * k1.c)))), z.c)
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
         rhs3<FAST>(P, gl, gx, gy, W, k6);
         kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(DP_A76, kx, ax); ay = PM_FMA(DP_A76, ky, ay);
-        ex = PM_FMA(DP_E6, kx, ex); ey = PM_FMA(DP_E6, ky, ey);
-#define ST7(c) PM_FMA(h, PM_FMA(DP_A76, k6.c, PM_FMA(DP_A75, k5.c, PM_FMA(DP_A74, k4.c, PM_FMA(DP_A73, k3.c, DP_A71 * k1.c)))), z.c)
+        ax = PM_FMA(T.a76, kx, ax); ay = PM_FMA(T.a76, ky, ay);
+        ex = PM_FMA(T.e6, kx, ex); ey = PM_FMA(T.e6, ky, ey);
+#define ST7(c) PM_FMA(h, PM_FMA(T.a76, k6.c, PM_FMA(T.a75, k5.c, PM_FMA(T.a74, k4.c, PM_FMA(T.a73, k3.c, T.a71 * k1.c)))), z.c)
         Vec5 un;
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax, z.x); un.y = PM_FMA(h, ay, z.y);
         rhs3<FAST>(P, un.lne, un.cx, un.cy, W, k7);
         st.rhs += 6;
         kx = un.cx * ipx; ky = un.cy * ipy;
-        ex = PM_FMA(DP_E7, kx, ex); ey = PM_FMA(DP_E7, ky, ey);
-#define ERRC(c) ((h * PM_FMA(DP_E7, k7.c, PM_FMA(DP_E6, k6.c, PM_FMA(DP_E5, k5.c, PM_FMA(DP_E4, k4.c, PM_FMA(DP_E3, k3.c, DP_E1 * k1.c)))))) / \
+        ex = PM_FMA(T.e7, kx, ex); ey = PM_FMA(T.e7, ky, ey);
+#define ERRC(c) ((h * PM_FMA(T.e7, k7.c, PM_FMA(T.e6, k6.c, PM_FMA(T.e5, k5.c, PM_FMA(T.e4, k4.c, PM_FMA(T.e3, k3.c, T.e1 * k1.c)))))) / \
                  PM_FMA(pm_max(pm_fabs(z.c), pm_fabs(un.c)), P.reltol, P.abstol))
         double EEst = rms5(ERRC(lne), ERRC(cx), ERRC(cy),
                            (h * ex) / PM_FMA(pm_max(pm_fabs(z.x), pm_fabs(un.x)), P.reltol, P.abstol),

@@ -168,6 +168,7 @@ template <bool FAST, bool STATIC>
 __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
                                                    int r0, int n0, int r1, int n1)
 {
+    dp_device_init();
     pm_device_init();
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
