@@ -59,3 +59,38 @@ def test_gpu_slabs_equal_single_context(tmp_path, name, world, halo):
         one.time_step(cfg.Δt)
     ref = one.get_state()
     assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
+
+
+def test_halo_blocks_are_zero_copy_torch_views():
+    """the RCCL path hands the library's own record memory to torch.distributed through
+    __cuda_array_interface__: the tensor must alias the halo block (read and write)."""
+    from picles_amd import configs, _capi as K
+    from picles_amd.models import build_structs
+    from picles_amd.driver import HipModel
+    from picles_amd.parallel import _DevBlock
+    from picles_amd import fetch_relations as FR
+    cfg = configs.bench06_box(n=32)
+    ms = FR.MinimalState(2, 2, cfg.model["ODEsets"].timestep)
+    g, p, o, m = build_structs(cfg.model["grid"], cfg.model["ODEsys"], cfg.model["ODEsets"], None, ms, True, j_begin=8, j_end=24)
+    hm = HipModel(g, p, o, m, mask=cfg.model["grid"].data.mask, device=0, halo_rows=2)
+    w = np.full((32, 16), 10.0)
+    hm.set_winds(w, w, 0.0)
+    hm.seed(0.0)
+    hm.begin_step(600.0, K.STEP_ZERO_FIRST)
+    hm.advance_rows(K.ROWS_ALL)
+    hm.sync()
+    ptr, nbytes = hm.halo_send(0)
+    assert nbytes == 2 * 6 * 32 * 8
+    t = torch.as_tensor(_DevBlock(ptr, nbytes), device="cuda")
+    assert t.data_ptr() == ptr and t.dtype == torch.float64 and t.numel() == nbytes // 8
+    rows = t.view(2, 6, 32)
+    assert torch.all(rows[:, 5, :] == 1.0)            # flag plane: every particle of the edge rows is on
+    assert torch.all(rows[:, 0, :] > 0)               # e plane
+    # write through the view into the ghost rows and see the scatter pick it up
+    rp, rb = hm.halo_recv(0)
+    ghost = torch.as_tensor(_DevBlock(rp, rb), device="cuda")
+    ghost.copy_(t)                                    # pretend the low neighbour sent our own edge rows
+    torch.cuda.synchronize()
+    hm.scatter_remesh()
+    S = hm.get_state()
+    assert S[:, 0, 0].min() > S[:, 8, 0].min() * 0.5  # edge row received contributions from the ghost rows
