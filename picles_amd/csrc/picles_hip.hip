@@ -12,7 +12,7 @@
  *   qold[n], dtn[n]  PI-controller memory ln(qold), next dt (<0 => auto_dt_reset!)
  *   on[n] u8, pflags[n] u8 (bit0 stepped, bit1 group-2 (mask 3), bit2 boundary), status[n] i32
  *   wind u0,v0,u1,v1 [n]
- *   rec[(ny_loc+2R)][6][Nx]   per-row scatter records e, m_x, m_y, x, y, flag of every particle
+ *   rec[(ny_loc+2R)][6][Nx]   per-row scatter records e, m_x, m_y, wx_hi, wy_hi, code(list, floor x, floor y)
  *                    (+R ghost rows per side = the halo blocks exchanged between slabs; a row
  *                    block is contiguous, so halo send/recv need no pack/unpack)
  *
@@ -113,6 +113,22 @@ __device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, lon
 __device__ __forceinline__ double *rec_row(const Arrays &A, const GridP &G, int row)
 {
     return A.rec + (size_t)row * 6 * G.Nx;
+}
+
+/* scatter record plane 5: 0.0 = no contribution, else list (1 ocean, 2 grid boundary) and the
+ * cell offsets (bx, by) = floor(x), floor(y) of the particle, packed into an exactly
+ * representable integer-valued double (the planes stay one dtype => contiguous halo blocks) */
+#define REC_BIAS 2048
+__device__ __forceinline__ double rec_encode(int grp, int bx, int by)
+{
+    return (double)(grp + 4 * (bx + REC_BIAS) + 4 * 4096 * (by + REC_BIAS));
+}
+__device__ __forceinline__ void rec_decode(double code, int &grp, int &bx, int &by)
+{
+    int ci = (int)code;
+    grp = ci & 3;
+    bx = ((ci >> 2) & 4095) - REC_BIAS;
+    by = (ci >> 14) - REC_BIAS;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -228,14 +244,12 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         if (status & (PICLES_ST_RESEED_NAN | PICLES_ST_RESEED_INF | PICLES_ST_SWITCHED_ON)) reseeds = 1;
         if (status & PICLES_ST_CLAMPED) clamps = 1;
         if (status & PICLES_ST_MAXITERS) maxit = 1;
-        /* scatter record */
+        /* scatter record: charge, upper-node weights and the packed (list, cell offset) code */
         double *rr = rec_row(A, G, jl + G.R);
-        double flag = 0.0;
+        double code = 0.0;
         if (on && pm_isfinite(z.x) && pm_isfinite(z.y)) {
             double e, mx, my;
             particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
-            rr[i] = e; rr[G.Nx + i] = mx; rr[2 * G.Nx + i] = my; rr[3 * G.Nx + i] = z.x; rr[4 * G.Nx + i] = z.y;
-            flag = (pf & PF_GROUP2) ? 2.0 : 1.0;
             int bx, by;
             double wx, wy;
             index_weight(z.x, bx, wx);
@@ -243,9 +257,13 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
             int r = (bx < 0) ? -bx : bx + 1;
             int ry = (by < 0) ? -by : by + 1;
             reach = (r > ry) ? r : ry;
-            if (G.Rp > 0 && reach > G.Rp) overflow = 1;
+            if (reach <= REC_BIAS - 1) {
+                rr[i] = e; rr[G.Nx + i] = mx; rr[2 * G.Nx + i] = my; rr[3 * G.Nx + i] = wx; rr[4 * G.Nx + i] = wy;
+                code = rec_encode((pf & PF_GROUP2) ? 2 : 1, bx, by);
+            }
+            if ((G.Rp > 0 && reach > G.Rp) || reach > REC_BIAS - 1) overflow = 1;
         }
-        rr[5 * G.Nx + i] = flag;
+        rr[5 * G.Nx + i] = code;
     }
     /* counters: wave-reduce, one atomic per wave */
     unsigned long long s_rhs = wave_sum_u64(st.rhs), s_acc = wave_sum_u64(st.acc), s_rej = wave_sum_u64(st.rej);
@@ -304,6 +322,58 @@ __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &
  * Fused: State zero-fill (accum=0), MovieState snapshot + post-remesh zero (movie=1),
  * remesh (REMESH).
  * ---------------------------------------------------------------------------------------- */
+/* sum of the contributions to node (i, j); RT > 0: reach known at compile time (fully unrolled:
+ * all candidate codes are loaded before any is inspected), RT == 0: runtime reach R */
+template <int RT>
+__device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i, int jl, int Rdyn,
+                                          double &s0, double &s1, double &s2)
+{
+    const int R = RT ? RT : Rdyn, W = 2 * R + 1;
+    const int RO = G.R;   /* row offset of the own rows inside rec */
+    const int j = jl + G.j_begin, Nx = G.Nx;
+    int shx = 0, shy = 0;
+    if (G.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= Nx) shx = Nx - i + R; }
+    if (G.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= G.Ny) shy = G.Ny - j + R; }
+    for (int grp = 1; grp <= G.ngroups; grp++) {
+#pragma unroll
+        for (int sj = 0; sj < (RT ? 2 * RT + 1 : W); sj++) {
+            int qj = sj + shy; if (qj >= W) qj -= W;
+            int dj = qj - R;
+            int jj = j + dj;
+            bool rowok = G.periodic_y || (jj >= 0 && jj < G.Ny);
+            int row;
+            if (G.single_slab) {
+                int jw = jj; if (jw < 0) jw += G.Ny; else if (jw >= G.Ny) jw -= G.Ny;
+                row = jw + RO;
+            } else {
+                row = jl + dj + RO;
+            }
+            if (!rowok) row = RO;   /* any valid row: the candidate is masked below */
+            const double *rr = rec_row(A, G, row);
+#pragma unroll
+            for (int si = 0; si < (RT ? 2 * RT + 1 : W); si++) {
+                int qi = si + shx; if (qi >= W) qi -= W;
+                int di = qi - R;
+                int ii = i + di;
+                bool ok = rowok;
+                if (ii < 0) { ok = ok && G.periodic_x; ii += Nx; }
+                else if (ii >= Nx) { ok = ok && G.periodic_x; ii -= Nx; }
+                double code = rr[5 * Nx + ii];
+                int cg, bx, by;
+                rec_decode(code, cg, bx, by);
+                int ax = -di - bx, ay = -dj - by;
+                if (ok && code != 0.0 && cg == grp && ax >= 0 && ax <= 1 && ay >= 0 && ay <= 1) {
+                    double wxh = rr[3 * Nx + ii], wyh = rr[4 * Nx + ii];
+                    double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
+                    s0 += w * rr[ii];
+                    s1 += w * rr[Nx + ii];
+                    s2 += w * rr[2 * Nx + ii];
+                }
+            }
+        }
+    }
+}
+
 template <bool REMESH>
 __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, int accum, int movie,
                                                    double clock, double DT)
@@ -313,54 +383,12 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
     unsigned int reseeds = 0;
     if (t < A.n) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
-        int j = jl + G.j_begin;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if (accum) { s0 = A.state[t]; s1 = A.state[t + A.n]; s2 = A.state[t + 2 * A.n]; }
         int R = G.Rp;
         if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
-        const int W = 2 * R + 1;
-        const int RO = G.R;   /* row offset of the own rows inside rec */
-        int shx = 0, shy = 0;
-        if (G.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= G.Nx) shx = G.Nx - i + R; }
-        if (G.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= G.Ny) shy = G.Ny - j + R; }
-        for (int grp = 1; grp <= G.ngroups; grp++) {
-            const double fgrp = (double)grp;
-            for (int sj = 0; sj < W; sj++) {
-                int qj = sj + shy; if (qj >= W) qj -= W;
-                int dj = qj - R;
-                int jj = j + dj;
-                if (!G.periodic_y && (jj < 0 || jj >= G.Ny)) continue;
-                int row;
-                if (G.single_slab) {
-                    int jw = jj; if (jw < 0) jw += G.Ny; else if (jw >= G.Ny) jw -= G.Ny;
-                    row = jw + RO;
-                } else {
-                    row = jl + dj + RO;
-                }
-                const double *rr = rec_row(A, G, row);
-                for (int si = 0; si < W; si++) {
-                    int qi = si + shx; if (qi >= W) qi -= W;
-                    int di = qi - R;
-                    int ii = i + di;
-                    if (ii < 0) { if (!G.periodic_x) continue; ii += G.Nx; }
-                    else if (ii >= G.Nx) { if (!G.periodic_x) continue; ii -= G.Nx; }
-                    if (rr[5 * G.Nx + ii] != fgrp) continue;
-                    double xs = rr[3 * G.Nx + ii], ys = rr[4 * G.Nx + ii];
-                    int bx, by;
-                    double wxh, wyh;
-                    index_weight(xs, bx, wxh);
-                    index_weight(ys, by, wyh);
-                    int ax = -di - bx, ay = -dj - by;
-                    if (ax < 0 || ax > 1 || ay < 0 || ay > 1) continue;
-                    double wx = ax ? wxh : 1.0 - wxh;
-                    double wy = ay ? wyh : 1.0 - wyh;
-                    double w = wx * wy;
-                    s0 += w * rr[ii];
-                    s1 += w * rr[G.Nx + ii];
-                    s2 += w * rr[2 * G.Nx + ii];
-                }
-            }
-        }
+        if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
+        else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
         if (movie) {
             A.movie[t] = s0; A.movie[t + A.n] = s1; A.movie[t + 2 * A.n] = s2;
             A.state[t] = 0.0; A.state[t + A.n] = 0.0; A.state[t + 2 * A.n] = 0.0;
@@ -442,26 +470,29 @@ __global__ void __launch_bounds__(256) k_push_tiles(GridP G, Arrays A, int ntx,
     else { base = seg_start[blockIdx.x]; count = seg_start[blockIdx.x + 1] - base; }
     for (int k = threadIdx.x; k < count; k += blockDim.x) {
         int ib, jb;          /* birth node, global */
-        double x, y, e, mx, my;
+        double x = 0.0, y = 0.0, e, mx, my;
+        int bx, by;
+        double wxh, wyh;
         if (IDENTITY) {
             ib = i0 + (k % PT_TX);
             jb = j0 + (k / PT_TX);
             int jl = jb - G.j_begin;
             if (ib >= G.Nx || jl >= G.ny_loc) continue;
             const double *rr = rec_row(A, G, jl + G.R);
-            if (rr[5 * G.Nx + ib] == 0.0) continue;
-            e = rr[ib]; mx = rr[G.Nx + ib]; my = rr[2 * G.Nx + ib]; x = rr[3 * G.Nx + ib]; y = rr[4 * G.Nx + ib];
+            double code = rr[5 * G.Nx + ib];
+            if (code == 0.0) continue;
+            int cg;
+            rec_decode(code, cg, bx, by);
+            e = rr[ib]; mx = rr[G.Nx + ib]; my = rr[2 * G.Nx + ib]; wxh = rr[3 * G.Nx + ib]; wyh = rr[4 * G.Nx + ib];
         } else {
             long long pidx = perm[base + k];
             ib = pij[pidx]; jb = pij[np + pidx];
             x = pxy[pidx]; y = pxy[np + pidx];
             e = pch[pidx]; mx = pch[np + pidx]; my = pch[2 * np + pidx];
             if (!(pm_isfinite(x) && pm_isfinite(y))) continue;
+            index_weight(x, bx, wxh);
+            index_weight(y, by, wyh);
         }
-        int bx, by;
-        double wxh, wyh;
-        index_weight(x, bx, wxh);
-        index_weight(y, by, wyh);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             int ax = c & 1, ay = c >> 1;

@@ -84,7 +84,7 @@ def test_halo_blocks_are_zero_copy_torch_views():
     t = torch.as_tensor(_DevBlock(ptr, nbytes), device="cuda")
     assert t.data_ptr() == ptr and t.dtype == torch.float64 and t.numel() == nbytes // 8
     rows = t.view(2, 6, 32)
-    assert torch.all(rows[:, 5, :] == 1.0)            # flag plane: every particle of the edge rows is on
+    assert torch.all(rows[:, 5, :] != 0.0)            # code plane: every particle of the edge rows contributes
     assert torch.all(rows[:, 0, :] > 0)               # e plane
     # write through the view into the ghost rows and see the scatter pick it up
     rp, rb = hm.halo_recv(0)
