@@ -39,7 +39,8 @@ def cpu_baseline(args, W, K):
     threads = min(cores, args.cpu_threads) if args.cpu_threads else cores
 
     def fac(g, p, o, m, mask, **kw):
-        return O.OracleModel(g, p, o, m, kind="pmath", order=1, threads=threads, mask=mask)
+        # pull=True: the node-parallel (OpenMP) scatter; bitwise equal to the sequential push
+        return O.OracleModel(g, p, o, m, kind="pmath", order=1, threads=threads, mask=mask, pull=True)
 
     def run(n):
         cfg = configs.box4096(n=n, U10=args.winds[0], V10=args.winds[1])
@@ -63,7 +64,7 @@ def cpu_baseline(args, W, K):
         rate, dt = run(n)
     return {"value": rate, "unit": "particle-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n}x{n} periodic sub-box, same physics/winds, same {W}+{K} steps, {dt:.1f} s of CPU work "
-                      f"(C oracle, OpenMP {threads} threads on {cores} host cores)"}
+                      f"(C oracle: OpenMP advance + node-parallel pull scatter, {threads} threads on {cores} host cores)"}
 
 
 def main():
