@@ -126,6 +126,18 @@ int32_t picles_abi_version(void);
 int32_t picles_set_winds(picles_ctx *ctx, const double *u0, const double *v0, double t0,
                          const double *u1, const double *v1, double t1);
 
+/* Gridded wind forcing (Utils/WindEmulator.jl:18-43 wind_interpolator =
+ * Interpolations.linear_interpolation((x,y,t), u; extrapolation_bc = Periodic())): u,v on a regular
+ * (x,y,t) lattice [nx*ny*nt], x fastest.  The library keeps the lattice in HBM and samples the two
+ * time levels of every step at the mesh nodes itself (tri-linear, periodic continuation), so no
+ * wind data crosses PCIe inside the time loop.  mesh_x0/mesh_y0: coordinates of node (0,0).
+ * Replaces picles_set_winds until picles_set_winds is called again. */
+int32_t picles_set_wind_grid(picles_ctx *ctx, int32_t nx, int32_t ny, int32_t nt,
+                             double x0, double dx, double y0, double dy, double t0, double dt,
+                             const double *u, const double *v, double mesh_x0, double mesh_y0);
+/* node winds currently on the device (own rows); any pointer may be NULL */
+int32_t picles_get_winds(picles_ctx *ctx, double *u0, double *v0, double *u1, double *v1);
+
 /* init_particles!(model) + SeedParticle (run.jl:199-247, core_2D.jl:434-488); clock := t0 */
 int32_t picles_seed(picles_ctx *ctx, double t0);
 

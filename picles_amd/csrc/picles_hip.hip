@@ -542,6 +542,60 @@ __global__ void k_tile_fill(long long np, const int *tile_of, const int *seg_sta
 }
 
 /* ------------------------------------------------------------------------------------------
+ * k_wind_sample — wind_interpolator (Utils/WindEmulator.jl:18-43): tri-linear interpolation of a
+ * regular (x,y,t) lattice to the mesh nodes at time t, periodic continuation outside the lattice
+ * (Interpolations.jl extrapolation_bc = Periodic(): period = last - first knot).
+ * ---------------------------------------------------------------------------------------- */
+struct WindGrid {
+    int nx, ny, nt;
+    double x0, inv_dx, y0, inv_dy, t0, inv_dt;
+    double mesh_x0, mesh_y0, mesh_dx, mesh_dy;
+    const double *u, *v;
+};
+
+__device__ __forceinline__ void lattice_coord(double c, int n, int &i0, double &f)
+{
+    /* c in lattice units; inside [0, n-1] as is, outside continued periodically */
+    double per = (double)(n - 1);
+    double w = (c < 0.0 || c > per) ? c - __builtin_floor(c / per) * per : c;
+    double fl = __builtin_floor(w);
+    i0 = (int)fl;
+    if (i0 > n - 2) i0 = n - 2;   /* w == per after rounding */
+    if (i0 < 0) i0 = 0;
+    f = w - (double)i0;
+}
+
+__global__ void __launch_bounds__(256) k_wind_sample(GridP G, WindGrid Wg, double t, double *uo, double *vo, long long n)
+{
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int i = (int)(k % G.Nx), j = (int)(k / G.Nx) + G.j_begin;
+    double x = Wg.mesh_x0 + (double)i * Wg.mesh_dx, y = Wg.mesh_y0 + (double)j * Wg.mesh_dy;
+    int ix, iy, it;
+    double fx, fy, ft;
+    lattice_coord((x - Wg.x0) * Wg.inv_dx, Wg.nx, ix, fx);
+    lattice_coord((y - Wg.y0) * Wg.inv_dy, Wg.ny, iy, fy);
+    lattice_coord((t - Wg.t0) * Wg.inv_dt, Wg.nt, it, ft);
+    size_t sx = 1, sy = (size_t)Wg.nx, st = (size_t)Wg.nx * Wg.ny;
+    size_t b = ix * sx + iy * sy + it * st;
+    const double *F[2] = {Wg.u, Wg.v};
+    double out[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const double *f = F[c];
+        double c00 = f[b] + (f[b + sx] - f[b]) * fx;
+        double c10 = f[b + sy] + (f[b + sy + sx] - f[b + sy]) * fx;
+        double c01 = f[b + st] + (f[b + st + sx] - f[b + st]) * fx;
+        double c11 = f[b + st + sy] + (f[b + st + sy + sx] - f[b + st + sy]) * fx;
+        double c0 = c00 + (c10 - c00) * fy;
+        double c1 = c01 + (c11 - c01) * fy;
+        out[c] = c0 + (c1 - c0) * ft;
+    }
+    uo[k] = out[0];
+    vo[k] = out[1];
+}
+
+/* ------------------------------------------------------------------------------------------
  * host side
  * ---------------------------------------------------------------------------------------- */
 static thread_local std::string g_create_error;
@@ -573,6 +627,12 @@ struct picles_ctx {
     std::vector<Ev> ev_used, ev_free;
     picles_timing tim{};
     std::string err;
+    /* gridded winds */
+    bool wind_grid_on = false;
+    WindGrid wg{};
+    double *d_wgu = nullptr, *d_wgv = nullptr;
+    double wind_t1 = 0.0;          /* time level currently held in (u1, v1) */
+    bool wind_t1_valid = false;
     /* generic scatter scratch */
     int *d_count = nullptr, *d_start = nullptr, *d_cursor = nullptr;
     void *d_scan_tmp = nullptr;
@@ -768,6 +828,8 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     hipFree(A.cnt); hipFree(A.max_reach); hipFree(A.rec); hipFree(c->d_mask);
+    if (c->d_wgu) hipFree(c->d_wgu);
+    if (c->d_wgv) hipFree(c->d_wgv);
     if (c->d_count) hipFree(c->d_count);
     if (c->d_start) hipFree(c->d_start);
     if (c->d_cursor) hipFree(c->d_cursor);
@@ -796,6 +858,7 @@ PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double
     if (!c || !u0 || !v0) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());   /* the previous step may still read the wind planes */
+    c->wind_grid_on = false;
     size_t b = (size_t)c->A.n * 8;
     HIPCHK(c, hipMemcpyAsync(c->A.u0, u0, b, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->A.v0, v0, b, hipMemcpyHostToDevice, c->stream));
@@ -816,11 +879,75 @@ PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double
 
 static inline unsigned nblocks(long long n, int b) { return (unsigned)((n + b - 1) / b); }
 
+PX_EXPORT int32_t picles_set_wind_grid(picles_ctx *c, int32_t nx, int32_t ny, int32_t nt,
+                                       double x0, double dx, double y0, double dy, double t0, double dt,
+                                       const double *u, const double *v, double mesh_x0, double mesh_y0)
+{
+    if (!c || !u || !v) return -1;
+    if (nx < 2 || ny < 2 || nt < 2 || !(dx > 0) || !(dy > 0) || !(dt > 0)) return fail(c, -2, "wind lattice needs >= 2 knots per axis and positive spacing");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->d_wgu) { hipFree(c->d_wgu); hipFree(c->d_wgv); c->d_wgu = c->d_wgv = nullptr; }
+    size_t nb = (size_t)nx * ny * nt * 8;
+    HIPCHK(c, hipMalloc(&c->d_wgu, nb));
+    HIPCHK(c, hipMalloc(&c->d_wgv, nb));
+    HIPCHK(c, hipMemcpy(c->d_wgu, u, nb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_wgv, v, nb, hipMemcpyHostToDevice));
+    WindGrid &w = c->wg;
+    w.nx = nx; w.ny = ny; w.nt = nt;
+    w.x0 = x0; w.inv_dx = 1.0 / dx; w.y0 = y0; w.inv_dy = 1.0 / dy; w.t0 = t0; w.inv_dt = 1.0 / dt;
+    w.mesh_x0 = mesh_x0; w.mesh_y0 = mesh_y0; w.mesh_dx = c->g.dx; w.mesh_dy = c->g.dy;
+    w.u = c->d_wgu; w.v = c->d_wgv;
+    c->wind_grid_on = true;
+    c->wind_t1_valid = false;
+    return 0;
+}
+
+/* sample the lattice for the step [t, t+dt] into (u0,v0) / (u1,v1); reuses the level the previous
+ * step left in (u1,v1) by swapping the plane pointers */
+static int wind_grid_prepare(picles_ctx *c, double t, double dt, hipStream_t s)
+{
+    Arrays &A = c->A;
+    dim3 grid(nblocks(A.n, 256)), block(256);
+    if (c->wind_t1_valid && c->wind_t1 == t) {
+        std::swap(A.u0, A.u1);
+        std::swap(A.v0, A.v1);
+    } else {
+        hipLaunchKernelGGL(k_wind_sample, grid, block, 0, s, c->G, c->wg, t, A.u0, A.v0, A.n);
+    }
+    hipLaunchKernelGGL(k_wind_sample, grid, block, 0, s, c->G, c->wg, t + dt, A.u1, A.v1, A.n);
+    HIPCHK(c, hipGetLastError());
+    c->wind_t1 = t + dt;
+    c->wind_t1_valid = true;
+    c->P.wind_static = 0;
+    c->P.tw0 = t;
+    c->P.inv_dtw = 1.0 / dt;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_get_winds(picles_ctx *c, double *u0, double *v0, double *u1, double *v1)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    size_t b = (size_t)c->A.n * 8;
+    if (u0) HIPCHK(c, hipMemcpy(u0, c->A.u0, b, hipMemcpyDeviceToHost));
+    if (v0) HIPCHK(c, hipMemcpy(v0, c->A.v0, b, hipMemcpyDeviceToHost));
+    if (u1) HIPCHK(c, hipMemcpy(u1, c->A.u1, b, hipMemcpyDeviceToHost));
+    if (v1) HIPCHK(c, hipMemcpy(v1, c->A.v1, b, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     c->clock = t0;
+    if (c->wind_grid_on) {   /* winds at t = 0.0 seed the particles (run.jl:213-215) */
+        c->wind_t1_valid = false;
+        int rc = wind_grid_prepare(c, 0.0, c->od.timestep, c->stream);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
     hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, c->A, c->d_mask, c->od.timestep);
@@ -854,6 +981,13 @@ PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
     c->step_flags = flags;
     c->edge_pending = false;
     c->step_fresh = true;   /* the first advance_rows of the step clears max_reach on ITS stream */
+    if (c->wind_grid_on) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());   /* previous step (any stream) done with the wind planes */
+        int rc = wind_grid_prepare(c, c->clock, dt, c->stream);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 

@@ -71,6 +71,18 @@ class HipModel:
         self._ck(self.lib.picles_set_winds(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(u1), K.dptr(v1), t1),
                  "picles_set_winds")
 
+    def set_wind_grid(self, lat: dict, mesh_x0: float, mesh_y0: float):
+        """upload an (x,y,t) wind lattice; the device samples it every step (picles_set_wind_grid)"""
+        self._wg = (lat["u"], lat["v"])
+        self._ck(self.lib.picles_set_wind_grid(self.h, lat["nx"], lat["ny"], lat["nt"], lat["x0"], lat["dx"], lat["y0"],
+                                               lat["dy"], lat["t0"], lat["dt"], K.dptr(lat["u"]), K.dptr(lat["v"]),
+                                               mesh_x0, mesh_y0), "picles_set_wind_grid")
+
+    def get_winds(self):
+        out = [np.empty(self.N) for _ in range(4)]
+        self._ck(self.lib.picles_get_winds(self.h, *[K.dptr(a) for a in out]), "picles_get_winds")
+        return [a.reshape((self.Nx, self.ny_loc), order="F") for a in out]
+
     def seed(self, t0=0.0):
         self._ck(self.lib.picles_seed(self.h, t0), "picles_seed")
 

@@ -153,6 +153,13 @@ class WaveGrowth2D:
 
     def upload_winds(self, t, dt):
         """node-sample the wind closures for the step [t, t+dt] (lerped in t by the kernel)"""
+        from .wind_emulator import GriddedWinds
+        if isinstance(self.winds, GriddedWinds) and hasattr(self.backend, "set_wind_grid"):
+            if self._wind_window != "device-lattice":      # once: the device samples every step itself
+                g = self.grid
+                self.backend.set_wind_grid(self.winds.lattice(), float(g.data.x[0, 0]), float(g.data.y[0, 0]))
+                self._wind_window = "device-lattice"
+            return
         if self._is_static(dt):
             if self._wind_window is None:
                 u, v = sample_winds(self.winds, self.grid, t)
