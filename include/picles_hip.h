@@ -155,6 +155,16 @@ int32_t picles_get_state(picles_ctx *ctx, double *state);
 int32_t picles_set_state(picles_ctx *ctx, const double *state);
 int32_t picles_get_movie_state(picles_ctx *ctx, double *state);
 
+/* ---- State snapshots for run!(…; store / cash_store) (run.jl:94-112, storing.jl:109-119) ----------
+ * push: stream-ordered device copy of State into a ring slot, then an asynchronous D2H copy into
+ * pinned host memory on a side stream — the next time steps overlap the PCIe transfer.
+ * pop: wait for the OLDEST pushed snapshot and hand it out (Nx*ny_loc*3 doubles + its model time).
+ * The host writes it wherever the store lives (HDF5 waves/data[time,x,y,state] in the reference). */
+int32_t picles_store_init(picles_ctx *ctx, int32_t n_slots);
+int32_t picles_store_push(picles_ctx *ctx);
+int32_t picles_store_pop(picles_ctx *ctx, double *state, double *time);
+int32_t picles_store_pending(const picles_ctx *ctx);
+
 /* particles (own rows; z is 5 planes: lne, c̄x, c̄y, x, y). Any pointer may be NULL. */
 int32_t picles_get_particles(picles_ctx *ctx, double *z, uint8_t *on, uint8_t *boundary,
                              int32_t *status);

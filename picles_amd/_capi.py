@@ -115,6 +115,10 @@ SYMBOLS = {
     "picles_get_state": (C.c_int32, [_VP, c_double_p]),
     "picles_set_state": (C.c_int32, [_VP, c_double_p]),
     "picles_get_movie_state": (C.c_int32, [_VP, c_double_p]),
+    "picles_store_init": (C.c_int32, [_VP, C.c_int32]),
+    "picles_store_push": (C.c_int32, [_VP]),
+    "picles_store_pop": (C.c_int32, [_VP, c_double_p, c_double_p]),
+    "picles_store_pending": (C.c_int32, [_VP]),
     "picles_get_particles": (C.c_int32, [_VP, c_double_p, c_uint8_p, c_uint8_p, c_int32_p]),
     "picles_set_particles": (C.c_int32, [_VP, c_double_p, c_uint8_p]),
     "picles_get_counters": (C.c_int32, [_VP, C.POINTER(PiclesCounters)]),

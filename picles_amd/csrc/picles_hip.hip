@@ -627,6 +627,12 @@ struct picles_ctx {
     std::vector<Ev> ev_used, ev_free;
     picles_timing tim{};
     std::string err;
+    /* snapshot ring (run! stores) */
+    int store_slots = 0, store_head = 0, store_count = 0;
+    std::vector<double *> store_dev, store_host;
+    std::vector<hipEvent_t> store_ready, store_done;
+    std::vector<double> store_time;
+    hipStream_t store_stream = nullptr;
     /* gridded winds */
     bool wind_grid_on = false;
     WindGrid wg{};
@@ -828,6 +834,11 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     hipFree(A.cnt); hipFree(A.max_reach); hipFree(A.rec); hipFree(c->d_mask);
+    for (auto p : c->store_dev) hipFree(p);
+    for (auto p : c->store_host) hipHostFree(p);
+    for (auto e : c->store_ready) hipEventDestroy(e);
+    for (auto e : c->store_done) hipEventDestroy(e);
+    if (c->store_stream) hipStreamDestroy(c->store_stream);
     if (c->d_wgu) hipFree(c->d_wgu);
     if (c->d_wgv) hipFree(c->d_wgv);
     if (c->d_count) hipFree(c->d_count);
@@ -1212,6 +1223,65 @@ PX_EXPORT int32_t picles_get_timing(picles_ctx *c, picles_timing *t)
     HIPCHK(c, hipSetDevice(c->device));
     timing_collect(c);
     *t = c->tim;
+    return 0;
+}
+
+/* ---- snapshot ring ---- */
+PX_EXPORT int32_t picles_store_init(picles_ctx *c, int32_t n_slots)
+{
+    if (!c || n_slots < 1) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->store_slots) return fail(c, -2, "store already initialised");
+    size_t b = 3 * (size_t)c->A.n * 8;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->store_stream, hipStreamNonBlocking));
+    for (int k = 0; k < n_slots; k++) {
+        double *d = nullptr, *h = nullptr;
+        hipEvent_t e1, e2;
+        HIPCHK(c, hipMalloc(&d, b));
+        HIPCHK(c, hipHostMalloc(&h, b, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        c->store_dev.push_back(d); c->store_host.push_back(h);
+        c->store_ready.push_back(e1); c->store_done.push_back(e2);
+    }
+    c->store_time.assign(n_slots, 0.0);
+    c->store_slots = n_slots; c->store_head = 0; c->store_count = 0;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_store_pending(const picles_ctx *c) { return c ? c->store_count : -1; }
+
+PX_EXPORT int32_t picles_store_push(picles_ctx *c)
+{
+    if (!c) return -1;
+    if (!c->store_slots) return fail(c, -2, "picles_store_init first");
+    if (c->store_count == c->store_slots) return fail(c, -3, "snapshot ring full: pop first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int slot = (c->store_head + c->store_count) % c->store_slots;
+    size_t b = 3 * (size_t)c->A.n * 8;
+    /* stream-ordered behind the step that produced State; the D2H leg runs beside the next steps */
+    HIPCHK(c, hipMemcpyAsync(c->store_dev[slot], c->A.state, b, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->store_ready[slot], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->store_stream, c->store_ready[slot], 0));
+    HIPCHK(c, hipMemcpyAsync(c->store_host[slot], c->store_dev[slot], b, hipMemcpyDeviceToHost, c->store_stream));
+    HIPCHK(c, hipEventRecord(c->store_done[slot], c->store_stream));
+    c->store_time[slot] = c->clock;
+    c->store_count++;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_store_pop(picles_ctx *c, double *state, double *time)
+{
+    if (!c || !state) return -1;
+    if (!c->store_count) return fail(c, -3, "no snapshot pending");
+    HIPCHK(c, hipSetDevice(c->device));
+    int slot = c->store_head;
+    HIPCHK(c, hipEventSynchronize(c->store_done[slot]));
+    memcpy(state, c->store_host[slot], 3 * (size_t)c->A.n * 8);
+    if (time) *time = c->store_time[slot];
+    c->store_head = (c->store_head + 1) % c->store_slots;
+    c->store_count--;
     return 0;
 }
 

@@ -151,6 +151,23 @@ class HipModel:
         self._ck(self.lib.picles_get_movie_state(self.h, K.dptr(s)), "picles_get_movie_state")
         return s.reshape((self.Nx, self.ny_loc, 3), order="F")
 
+    # ---- snapshot ring ----
+    def store_init(self, n_slots=3):
+        self._ck(self.lib.picles_store_init(self.h, n_slots), "picles_store_init")
+
+    def store_push(self):
+        self._ck(self.lib.picles_store_push(self.h), "picles_store_push")
+
+    def store_pop(self):
+        s = np.empty(3 * self.N)
+        t = C.c_double()
+        self._ck(self.lib.picles_store_pop(self.h, K.dptr(s), C.byref(t)), "picles_store_pop")
+        return s.reshape((self.Nx, self.ny_loc, 3), order="F"), t.value
+
+    @property
+    def store_pending(self):
+        return self.lib.picles_store_pending(self.h)
+
     def get_particles(self):
         z = np.empty(5 * self.N)
         on = np.empty(self.N, dtype=np.uint8)

@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import time
 
+import numpy as np
+
 from .timesteppers import time_step
 
 
@@ -12,6 +14,41 @@ class CashStore:
     def __init__(self):
         self.store = []
         self.iteration = 1
+
+
+class StateStore:
+    """Counterpart of the reference's HDF5 StateStore (storing.jl:36-62,109-119): the dataset
+    `waves/data[time, x, y, state]` with `var_names = ["e","m_x","m_y"]` and the coordinate vectors.
+    HDF5 bindings are not available in this image, so the same logical layout is written as a NumPy
+    `.npy` memory map plus a JSON side-car; the device→host path (asynchronous snapshot ring) is what
+    the library provides either way."""
+
+    def __init__(self, path, time, x, y, name="state"):
+        import json
+        from pathlib import Path
+        self.dir = Path(path)
+        self.dir.mkdir(parents=True, exist_ok=True)
+        self.shape = (len(time), len(x), len(y), 3)
+        self.data = np.lib.format.open_memmap(self.dir / f"{name}.waves.data.npy", mode="w+", dtype=np.float64, shape=self.shape)
+        (self.dir / f"{name}.json").write_text(json.dumps(
+            {"group": "waves", "dims": ["time", "x", "y", "state"], "var_names": ["e", "m_x", "m_y"],
+             "time": list(map(float, time)), "x": list(map(float, x)), "y": list(map(float, y))}))
+        self.iteration = 0
+
+    def write(self, state):
+        self.data[self.iteration] = state
+        self.iteration += 1
+
+    def close(self):
+        self.data.flush()
+
+
+def init_state_store(sim, save_path, name="state"):
+    """init_state_store!(sim, save_path) (storing.jl:83-104)"""
+    g = sim.model.grid
+    times = np.arange(0.0, sim.stop_time + sim.Δt + 0.5 * sim.Δt, sim.Δt)
+    sim.store = StateStore(save_path, times, g.data.x[:, 0], g.data.y[0, :], name=name)
+    return sim.store
 
 
 class Simulation:
@@ -52,9 +89,10 @@ def reset_simulation(sim: Simulation):
 
 def run(sim: Simulation, store=False, pickup=False, cash_store=False, debug=False):
     """run!(sim) (run.jl:36-122): note `stop_time >= clock.time`, i.e. one step past stop_time."""
-    if store:
-        raise NotImplementedError("HDF5 StateStore is out of scope; use cash_store=True")
     t0 = time.perf_counter_ns()
+    if store and not isinstance(sim.store, StateStore):
+        raise ValueError("call init_state_store(sim, path) before run(sim, store=True)")
+    ring = store and hasattr(sim.model.backend, "store_init")
     if not sim.initialized:
         initialize_simulation(sim)
     sim.run_wall_time = 0.0
@@ -63,12 +101,31 @@ def run(sim: Simulation, store=False, pickup=False, cash_store=False, debug=Fals
         sim.store = CashStore()
         sim.store.iteration += 1
         sim.store.store.append(sim.model.State.copy())
+    if store:
+        sim.store.write(sim.model.State)          # initial state (run.jl:62-69)
+        if ring and not getattr(sim.model.backend, "_store_ready", False):
+            sim.model.backend.store_init(3)
+            sim.model.backend._store_ready = True
     while sim.running:
         # State .= 0 is fused into the scatter kernel (zero_first)
         time_step(sim.model, sim.Δt, debug=debug, zero_first=True)
+        if store:
+            if ring:   # asynchronous: D2H of step k overlaps the kernels of steps k+1, k+2
+                b = sim.model.backend
+                if b.store_pending == 3:
+                    sim.store.write(b.store_pop()[0])
+                b.store_push()
+            else:
+                sim.store.write(sim.model.State)
         if cash_store:
             sim.store.store.append(sim.model.State.copy())
             sim.store.iteration += 1
         sim.running = sim.stop_time >= sim.model.clock.time
+    if store:
+        if ring:
+            b = sim.model.backend
+            while b.store_pending:
+                sim.store.write(b.store_pop()[0])
+        sim.store.close()
     sim.model.backend.sync() if hasattr(sim.model.backend, "sync") else None
     sim.run_wall_time += 1e-9 * (time.perf_counter_ns() - t0)

@@ -242,3 +242,21 @@ def test_full_size_4096_properties():
     for _ in range(3):
         m2.backend.time_step(cfg.Δt, K.STEP_ZERO_FIRST)
     assert np.array_equal(m2.backend.get_state(), S)
+
+
+def test_run_with_async_state_store(tmp_path):
+    """run!(sim, store=true): snapshots travel through the device ring + async D2H and land in the
+    waves/data[time,x,y,state] layout; they must equal the synchronous cash_store copies."""
+    from picles_amd.simulations import run, init_state_store
+    cfg = configs.example_00_minimal(n=41, L=80e3)
+    a = make_model(cfg, "hip")
+    sim = Simulation(a, Δt=cfg.Δt, stop_time=cfg.stop_time)
+    init_state_store(sim, tmp_path)
+    run(sim, store=True)
+    data = np.load(tmp_path / "state.waves.data.npy")
+    b = make_model(configs.example_00_minimal(n=41, L=80e3), "hip")
+    sim2 = Simulation(b, Δt=cfg.Δt, stop_time=cfg.stop_time)
+    run(sim2, cash_store=True)
+    assert data.shape[0] >= 14 and len(sim2.store.store) == 14
+    for k in range(14):
+        assert np.array_equal(data[k], sim2.store.store[k]), k
