@@ -69,9 +69,11 @@ struct Arrays {
     unsigned char *on, *pflags;
     int *status;
     double *u0, *v0, *u1, *v1;
-    double *rec;
+    double *rec;             /* records the scatter reads  (latest completed advance) */
+    double *rec_out;         /* records the advance writes (the other buffer of the pair) */
     DevCounters *cnt;        /* [NSLOTS] */
-    int *max_reach;          /* per-step max scatter reach (read by the pull kernel) */
+    int *max_reach;          /* max scatter reach of the records in `rec` (read by the pull) */
+    int *max_reach_out;      /* ... of the records being written to `rec_out` */
     long long n;             /* Nx * ny_loc */
 };
 
@@ -113,6 +115,10 @@ __device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, lon
 __device__ __forceinline__ double *rec_row(const Arrays &A, const GridP &G, int row)
 {
     return A.rec + (size_t)row * 6 * G.Nx;
+}
+__device__ __forceinline__ double *rec_row_out(const Arrays &A, const GridP &G, int row)
+{
+    return A.rec_out + (size_t)row * 6 * G.Nx;
 }
 
 /* scatter record plane 5: 0.0 = no contribution, else list (1 ocean, 2 grid boundary) and the
@@ -175,101 +181,90 @@ __global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, cons
 }
 
 /* ------------------------------------------------------------------------------------------
- * k_advance — advance! (mapping_2D.jl:118-243) for the particles of local rows
- * [r0, r0+n0) ∪ [r1, r1+n1).  One thread per particle; the whole adaptive RK loop runs in
- * registers.  Writes the particle's scatter record (ParticleToNode! inputs) instead of
- * scattering: the scatter itself is k_scatter / k_push_tiles.
+ * advance! (mapping_2D.jl:118-243) of one particle held in registers: integrate / off->on test,
+ * NaN / Inf / cap guards.  Shared by k_advance and the fused k_step.
  * ---------------------------------------------------------------------------------------- */
-template <bool FAST, bool STATIC>
-__global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
-                                                   int r0, int n0, int r1, int n1)
-{
-    dp_device_init();
-    pm_device_init();
-    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
-    bool active = tid < na + nb;
-    long long t = 0;
-    if (active) t = (tid < na) ? (long long)r0 * G.Nx + tid : (long long)r1 * G.Nx + (tid - na);
-    unsigned char pf = active ? A.pflags[t] : 0;
-    active = active && (pf & PF_STEPPED);
+struct StepStats {
+    PStats st;
+    unsigned int adv, reseeds, clamps, maxit, overflow;
+    int reach;
+};
 
-    PStats st = {0u, 0u, 0u, 0};
-    unsigned int adv = 0, reseeds = 0, clamps = 0, maxit = 0, overflow = 0;
-    int reach = 0;
-    if (active) {
-        int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
-        Vec5 z;
-        z.lne = A.z[t]; z.cx = A.z[t + A.n]; z.cy = A.z[t + 2 * A.n]; z.x = A.z[t + 3 * A.n]; z.y = A.z[t + 4 * A.n];
-        int on = A.on[t];
-        double qold = A.qold[t], dtn = A.dtn[t];
-        Wind w = load_wind(P, A, t);
-        int status = PICLES_ST_STEPPED;
-        if (on) {
-            adv = 1;
-            integrate_dp5<FAST, STATIC>(P, w, z, qold, dtn, t_start, DT, st);
-            status |= st.status;
-        } else {
-            double u, v;
-            wind_at(P, w, t_start + DT, u, v);
-            if (u * u + v * v >= P.wind_min_sq) {
-                reseed(P, u, v, DT, z);
-                dtn = -1.0;
-                on = 1;
-                status |= PICLES_ST_SWITCHED_ON;
-            }
-        }
-        if (pm_isnan(z.lne) || pm_isnan(z.cx) || pm_isnan(z.cy)) {
-            double u, v;
-            wind_at(P, w, t_start + DT, u, v);
+template <bool FAST, bool STATIC>
+__device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
+                                                double &dtn, double t_start, double DT, StepStats &S)
+{
+    int status = PICLES_ST_STEPPED;
+    if (on) {
+        S.adv = 1;
+        integrate_dp5<FAST, STATIC>(P, w, z, qold, dtn, t_start, DT, S.st);
+        status |= S.st.status;
+    } else {
+        double u, v;
+        wind_at(P, w, t_start + DT, u, v);
+        if (u * u + v * v >= P.wind_min_sq) {
             reseed(P, u, v, DT, z);
             dtn = -1.0;
-            status |= PICLES_ST_RESEED_NAN;
-        } else if (pm_isinf(z.lne) || pm_isinf(z.cx) || pm_isinf(z.cy)) {
-            double u, v;
-            wind_at(P, w, t_start, u, v);
-            reseed(P, u, v, DT, z);
-            dtn = -1.0;
-            status |= PICLES_ST_RESEED_INF;
-        } else if (z.lne > P.lne_max) {
-            z.lne = P.lne_max;
-            dtn = -1.0;
-            status |= PICLES_ST_CLAMPED;
+            on = 1;
+            status |= PICLES_ST_SWITCHED_ON;
         }
-        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
-        A.on[t] = (unsigned char)on;
-        A.qold[t] = qold;
-        A.dtn[t] = dtn;
-        A.status[t] = status;
-        if (status & (PICLES_ST_RESEED_NAN | PICLES_ST_RESEED_INF | PICLES_ST_SWITCHED_ON)) reseeds = 1;
-        if (status & PICLES_ST_CLAMPED) clamps = 1;
-        if (status & PICLES_ST_MAXITERS) maxit = 1;
-        /* scatter record: charge, upper-node weights and the packed (list, cell offset) code */
-        double *rr = rec_row(A, G, jl + G.R);
-        double code = 0.0;
-        if (on && pm_isfinite(z.x) && pm_isfinite(z.y)) {
-            double e, mx, my;
-            particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
-            int bx, by;
-            double wx, wy;
-            index_weight(z.x, bx, wx);
-            index_weight(z.y, by, wy);
-            int r = (bx < 0) ? -bx : bx + 1;
-            int ry = (by < 0) ? -by : by + 1;
-            reach = (r > ry) ? r : ry;
-            if (reach <= REC_BIAS - 1) {
-                rr[i] = e; rr[G.Nx + i] = mx; rr[2 * G.Nx + i] = my; rr[3 * G.Nx + i] = wx; rr[4 * G.Nx + i] = wy;
-                code = rec_encode((pf & PF_GROUP2) ? 2 : 1, bx, by);
-            }
-            if ((G.Rp > 0 && reach > G.Rp) || reach > REC_BIAS - 1) overflow = 1;
-        }
-        rr[5 * G.Nx + i] = code;
     }
-    /* counters: wave-reduce, one atomic per wave */
-    unsigned long long s_rhs = wave_sum_u64(st.rhs), s_acc = wave_sum_u64(st.acc), s_rej = wave_sum_u64(st.rej);
-    unsigned long long s_adv = wave_sum_u64(adv), s_res = wave_sum_u64(reseeds), s_cl = wave_sum_u64(clamps);
-    unsigned long long s_mx = wave_sum_u64(maxit), s_ov = wave_sum_u64(overflow);
-    int m_reach = wave_max_i32(reach);
+    if (pm_isnan(z.lne) || pm_isnan(z.cx) || pm_isnan(z.cy)) {
+        double u, v;
+        wind_at(P, w, t_start + DT, u, v);
+        reseed(P, u, v, DT, z);
+        dtn = -1.0;
+        status |= PICLES_ST_RESEED_NAN;
+    } else if (pm_isinf(z.lne) || pm_isinf(z.cx) || pm_isinf(z.cy)) {
+        double u, v;
+        wind_at(P, w, t_start, u, v);
+        reseed(P, u, v, DT, z);
+        dtn = -1.0;
+        status |= PICLES_ST_RESEED_INF;
+    } else if (z.lne > P.lne_max) {
+        z.lne = P.lne_max;
+        dtn = -1.0;
+        status |= PICLES_ST_CLAMPED;
+    }
+    if (status & (PICLES_ST_RESEED_NAN | PICLES_ST_RESEED_INF | PICLES_ST_SWITCHED_ON)) S.reseeds = 1;
+    if (status & PICLES_ST_CLAMPED) S.clamps = 1;
+    if (status & PICLES_ST_MAXITERS) S.maxit = 1;
+    return status;
+}
+
+/* scatter record of one advanced particle (ParticleToNode! inputs): charge, upper-node weights and
+ * the packed (list, cell offset) code, into the OUT buffer */
+__device__ __forceinline__ void write_record(const GridP &G, const Arrays &A, int i, int jl, unsigned char pf, int on,
+                                             const Vec5 &z, StepStats &S)
+{
+    double *rr = rec_row_out(A, G, jl + G.R);
+    double code = 0.0;
+    if (on && pm_isfinite(z.x) && pm_isfinite(z.y)) {
+        double e, mx, my;
+        particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
+        int bx, by;
+        double wx, wy;
+        index_weight(z.x, bx, wx);
+        index_weight(z.y, by, wy);
+        int r = (bx < 0) ? -bx : bx + 1;
+        int ry = (by < 0) ? -by : by + 1;
+        S.reach = (r > ry) ? r : ry;
+        if (S.reach <= REC_BIAS - 1) {
+            rr[i] = e; rr[G.Nx + i] = mx; rr[2 * G.Nx + i] = my; rr[3 * G.Nx + i] = wx; rr[4 * G.Nx + i] = wy;
+            code = rec_encode((pf & PF_GROUP2) ? 2 : 1, bx, by);
+        }
+        if ((G.Rp > 0 && S.reach > G.Rp) || S.reach > REC_BIAS - 1) S.overflow = 1;
+    }
+    rr[5 * G.Nx + i] = code;
+}
+
+/* statistics: wave-reduce, one atomic per wave into the wave's slot */
+__device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
+{
+    unsigned long long s_rhs = wave_sum_u64(S.st.rhs), s_acc = wave_sum_u64(S.st.acc), s_rej = wave_sum_u64(S.st.rej);
+    unsigned long long s_adv = wave_sum_u64(S.adv), s_res = wave_sum_u64(S.reseeds), s_cl = wave_sum_u64(S.clamps);
+    unsigned long long s_mx = wave_sum_u64(S.maxit), s_ov = wave_sum_u64(S.overflow);
+    int m_reach = wave_max_i32(S.reach);
     if ((threadIdx.x & 63) == 0) {
         DevCounters *c = A.cnt + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (NSLOTS - 1));
         if (s_rhs) atomicAdd(&c->rhs, s_rhs);
@@ -281,34 +276,87 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         if (s_mx) atomicAdd(&c->maxit, s_mx);
         if (s_ov) atomicAdd(&c->overflow, s_ov);
         /* one address for the whole grid: only waves that would raise it touch it */
-        if (m_reach > __hip_atomic_load(A.max_reach, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(A.max_reach, m_reach);
+        if (m_reach > __hip_atomic_load(A.max_reach_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(A.max_reach_out, m_reach);
     }
 }
 
-/* NodeToParticle! (mapping_2D.jl:279-356) on the node value (e,mx,my) held in registers */
+/* local rows [r0, r0+n0) ∪ [r1, r1+n1) -> particle index */
+__device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r1, int n1, long long &t)
+{
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
+    if (tid >= na + nb) return false;
+    t = (tid < na) ? (long long)r0 * G.Nx + tid : (long long)r1 * G.Nx + (tid - na);
+    return true;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_advance — advance! for the particles of the given rows.  One thread per particle; the whole
+ * adaptive RK loop runs in registers.  Writes the particle's scatter record instead of
+ * scattering: the scatter itself is k_scatter / k_step / k_push_tiles.
+ * ---------------------------------------------------------------------------------------- */
+template <bool FAST, bool STATIC>
+__global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
+                                                   int r0, int n0, int r1, int n1)
+{
+    dp_device_init();
+    pm_device_init();
+    long long t = 0;
+    bool active = rows_index(G, r0, n0, r1, n1, t);
+    unsigned char pf = active ? A.pflags[t] : 0;
+    active = active && (pf & PF_STEPPED);
+    StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0};
+    if (active) {
+        int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
+        Vec5 z;
+        z.lne = A.z[t]; z.cx = A.z[t + A.n]; z.cy = A.z[t + 2 * A.n]; z.x = A.z[t + 3 * A.n]; z.y = A.z[t + 4 * A.n];
+        int on = A.on[t];
+        double qold = A.qold[t], dtn = A.dtn[t];
+        Wind w = load_wind(P, A, t);
+        int status = advance_particle<FAST, STATIC>(P, w, z, on, qold, dtn, t_start, DT, S);
+        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
+        A.on[t] = (unsigned char)on;
+        A.qold[t] = qold;
+        A.dtn[t] = dtn;
+        A.status[t] = status;
+        write_record(G, A, i, jl, pf, on, z, S);
+    }
+    flush_stats(A, S);
+}
+
+/* NodeToParticle! (mapping_2D.jl:279-356) on the node value (e,mx,my), all in registers.
+ * Returns the branch: 0 = A (node -> particle), 1 = B/C (re-seed from the wind), 2 = D (off). */
+__device__ __forceinline__ int remesh_regs(const KParams &P, const Wind &w, unsigned char pf, double e, double mx,
+                                           double my, double clock, double DT, Vec5 &z)
+{
+    double u, v;
+    wind_at(P, w, clock, u, v);          /* winds at model.clock.time, before tick! */
+    bool bnd = (pf & PF_BOUNDARY) != 0;
+    if (!bnd && (e >= P.min_e) && (mx * mx + my * my >= P.min_m2)) {
+        charge_to_particle(e, mx, my, z);
+        return 0;
+    }
+    if (u * u + v * v >= P.wind_min_sq) {
+        reseed(P, u, v, DT, z);
+        return 1;
+    }
+    return 2;
+}
+
 __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &A, long long t, unsigned char pf,
                                                 double e, double mx, double my, double clock, double DT,
                                                 unsigned int &reseeds)
 {
     Wind w = load_wind(P, A, t);
-    double u, v;
-    wind_at(P, w, clock, u, v);          /* winds at model.clock.time, before tick! */
-    bool bnd = (pf & PF_BOUNDARY) != 0;
     Vec5 z;
-    if (!bnd && (e >= P.min_e) && (mx * mx + my * my >= P.min_m2)) {          /* A */
-        charge_to_particle(e, mx, my, z);
+    int br = remesh_regs(P, w, pf, e, mx, my, clock, DT, z);
+    if (br <= 1) {
         A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
+        if (br == 1) { A.qold[t] = PI_LNQOLDINIT; reseeds = 1; }   /* reinit! */
         A.dtn[t] = -1.0;
         A.on[t] = 1;
-    } else if (u * u + v * v >= P.wind_min_sq) {                               /* B, C */
-        reseed(P, u, v, DT, z);
-        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
-        A.qold[t] = PI_LNQOLDINIT;   /* reinit! */
-        A.dtn[t] = -1.0;
-        A.on[t] = 1;
-        reseeds = 1;
-    } else {                                                                    /* D */
+    } else {
         A.on[t] = 0;
     }
 }
@@ -405,6 +453,53 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
         if ((threadIdx.x & 63) == 0 && s)
             atomicAdd(&A.cnt[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (NSLOTS - 1)].reseeds, s);
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_step — one whole model step per launch, for consecutive run!-style steps (State zeroed
+ * before each step, time-constant winds): the thread of node/particle k
+ *   1. pull-scatters the PREVIOUS step's records -> State[k]          (k_scatter)
+ *   2. remeshes particle k from that node value, in registers          (NodeToParticle!)
+ *   3. advances it over the CURRENT step and writes its new record into the other record buffer
+ * The particle state never round-trips through HBM: per step only records (48 B), State (24 B),
+ * winds (16 B), ln(qold) (8+8 B) and status move.  The last step's scatter+remesh is done by a
+ * stand-alone k_scatter when somebody looks (flush()).  Results are bit-identical to the
+ * k_advance + k_scatter sequence.
+ * ---------------------------------------------------------------------------------------- */
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
+                                                double t_start, double DT)
+{
+    dp_device_init();
+    pm_device_init();
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0};
+    if (t < A.n) {
+        int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        int R = G.Rp;
+        if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
+        if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
+        else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
+        A.state[t] = s0; A.state[t + A.n] = s1; A.state[t + 2 * A.n] = s2;
+        unsigned char pf = A.pflags[t];
+        if (pf & PF_STEPPED) {
+            Wind w = load_wind(P, A, t);
+            Vec5 z = {0.0, 0.0, 0.0, 0.0, 0.0};
+            double qold = A.qold[t], dtn = -1.0;
+            int br = remesh_regs(P, w, pf, s0, s1, s2, t_prev, DT_prev, z);
+            int on = (br <= 1);
+            if (br == 1) { qold = PI_LNQOLDINIT; S.reseeds = 1; }
+            unsigned int rs = S.reseeds;
+            S.reseeds = 0;
+            int status = advance_particle<FAST, true>(P, w, z, on, qold, dtn, t_start, DT, S);
+            S.reseeds += rs;
+            A.qold[t] = qold;
+            A.status[t] = status;
+            write_record(G, A, i, jl, pf, on, z, S);
+        }
+    }
+    flush_stats(A, S);
 }
 
 /* stand-alone time_step!_remesh (TimeSteppers.jl:182-193) */
@@ -613,6 +708,14 @@ struct picles_ctx {
     hipEvent_t ev_edge;
     bool edge_pending = false;
     bool step_fresh = false;
+    /* record buffer pair: rec_buf[cur] belongs to the step in flight / last completed advance */
+    double *rec_buf[2] = {nullptr, nullptr};
+    int *mr_buf[2] = {nullptr, nullptr};
+    int cur = 0;
+    /* fused stepping: the last advance's records still await their scatter + remesh */
+    bool fuse_steps = true;
+    bool pending = false;
+    double pend_t = 0.0, pend_dt = 0.0;
     signed char *d_mask = nullptr;
     std::vector<signed char> h_mask;
     double clock = 0.0;
@@ -694,13 +797,32 @@ static void timing_collect(picles_ctx *c)
 
 static size_t rec_bytes(const picles_ctx *c) { return (size_t)(c->G.ny_loc + 2 * c->G.R) * 6 * c->G.Nx * sizeof(double); }
 
-static int alloc_rec(picles_ctx *c)
+/* Arrays as a kernel sees them: which record buffer is read (scatter) / written (advance) */
+static Arrays arrays_for(picles_ctx *c, int read_buf, int write_buf)
 {
-    if (c->A.rec) HIPCHK(c, hipFree(c->A.rec));
-    c->A.rec = nullptr;
-    HIPCHK(c, hipMalloc(&c->A.rec, rec_bytes(c)));
-    HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
-    return 0;
+    Arrays A = c->A;
+    A.rec = c->rec_buf[read_buf];
+    A.rec_out = c->rec_buf[write_buf];
+    A.max_reach = c->mr_buf[read_buf];
+    A.max_reach_out = c->mr_buf[write_buf];
+    return A;
+}
+
+static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh);
+
+/* scatter + remesh of the last fused step, if still outstanding */
+static int flush(picles_ctx *c)
+{
+    if (!c->pending) return 0;
+    c->pending = false;
+    double clock_save = c->clock, dt_save = c->step_dt;
+    int flags_save = c->step_flags;
+    c->clock = c->pend_t;           /* remesh samples the wind at the start-of-step clock */
+    c->step_dt = c->pend_dt;
+    c->step_flags = PICLES_STEP_ZERO_FIRST;
+    int rc = launch_scatter(c, c->stream, true);
+    c->clock = clock_save; c->step_dt = dt_save; c->step_flags = flags_save;
+    return rc;
 }
 
 PX_EXPORT int32_t picles_abi_version(void) { return PICLES_ABI_VERSION; }
@@ -808,8 +930,12 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     CK(hipMalloc(&A.on, n)); CK(hipMalloc(&A.pflags, n)); CK(hipMalloc(&A.status, n * 4));
     CK(hipMalloc(&A.u0, n * 8)); CK(hipMalloc(&A.v0, n * 8)); CK(hipMalloc(&A.u1, n * 8)); CK(hipMalloc(&A.v1, n * 8));
     CK(hipMalloc(&A.cnt, NSLOTS * sizeof(DevCounters)));
-    CK(hipMalloc(&A.max_reach, sizeof(int)));
-    CK(hipMemset(A.max_reach, 0, sizeof(int)));
+    for (int k = 0; k < 2; k++) {
+        CK(hipMalloc(&c->mr_buf[k], sizeof(int)));
+        CK(hipMemset(c->mr_buf[k], 0, sizeof(int)));
+        CK(hipMalloc(&c->rec_buf[k], rec_bytes(c)));
+        CK(hipMemset(c->rec_buf[k], 0, rec_bytes(c)));
+    }
     CK(hipMalloc(&c->d_mask, n));
     CK(hipMemset(A.state, 0, 3 * n * 8)); CK(hipMemset(A.movie, 0, 3 * n * 8)); CK(hipMemset(A.z, 0, 5 * n * 8));
     CK(hipMemset(A.qold, 0, n * 8)); CK(hipMemset(A.dtn, 0, n * 8)); CK(hipMemset(A.on, 0, n)); CK(hipMemset(A.status, 0, n * 4));
@@ -817,8 +943,6 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     CK(hipMemset(A.cnt, 0, NSLOTS * sizeof(DevCounters)));
     CK(hipMemcpy(A.pflags, pf.data(), n, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_mask, c->h_mask.data(), n, hipMemcpyHostToDevice));
-    CK(hipMalloc(&A.rec, rec_bytes(c)));
-    CK(hipMemset(A.rec, 0, rec_bytes(c)));
 #undef CK
     c->state_zero = true;
     *out = c;
@@ -833,7 +957,8 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     Arrays &A = c->A;
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
-    hipFree(A.cnt); hipFree(A.max_reach); hipFree(A.rec); hipFree(c->d_mask);
+    hipFree(A.cnt); hipFree(c->d_mask);
+    for (int k = 0; k < 2; k++) { hipFree(c->rec_buf[k]); hipFree(c->mr_buf[k]); }
     for (auto p : c->store_dev) hipFree(p);
     for (auto p : c->store_host) hipHostFree(p);
     for (auto e : c->store_ready) hipEventDestroy(e);
@@ -857,6 +982,7 @@ PX_EXPORT int32_t picles_sync(picles_ctx *c)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());
     return 0;
 }
@@ -868,6 +994,7 @@ PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double
 {
     if (!c || !u0 || !v0) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());   /* the previous step may still read the wind planes */
     c->wind_grid_on = false;
     size_t b = (size_t)c->A.n * 8;
@@ -897,6 +1024,7 @@ PX_EXPORT int32_t picles_set_wind_grid(picles_ctx *c, int32_t nx, int32_t ny, in
     if (!c || !u || !v) return -1;
     if (nx < 2 || ny < 2 || nt < 2 || !(dx > 0) || !(dy > 0) || !(dt > 0)) return fail(c, -2, "wind lattice needs >= 2 knots per axis and positive spacing");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());
     if (c->d_wgu) { hipFree(c->d_wgu); hipFree(c->d_wgv); c->d_wgu = c->d_wgv = nullptr; }
     size_t nb = (size_t)nx * ny * nt * 8;
@@ -959,9 +1087,14 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
         int rc = wind_grid_prepare(c, 0.0, c->od.timestep, c->stream);
         if (rc) return rc;
     }
-    HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
+    c->pending = false;
+    c->cur = 0;
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(c, hipMemsetAsync(c->rec_buf[k], 0, rec_bytes(c), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->mr_buf[k], 0, sizeof(int), c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
-    hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, c->A, c->d_mask, c->od.timestep);
+    hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, arrays_for(c, 0, 0), c->d_mask, c->od.timestep);
     HIPCHK(c, hipGetLastError());
     c->state_zero = false;
     c->seeded = true;
@@ -972,6 +1105,7 @@ PX_EXPORT int32_t picles_zero_state(picles_ctx *c)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipMemsetAsync(c->A.state, 0, 3 * c->A.n * 8, c->stream));
     c->state_zero = true;
     return 0;
@@ -988,9 +1122,11 @@ PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
 {
     if (!c) return -1;
     if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
+    { int rc = flush(c); if (rc) return rc; }
     c->step_dt = dt;
     c->step_flags = flags;
     c->edge_pending = false;
+    c->cur ^= 1;            /* this step's records go to (and are scattered from) rec_buf[cur] */
     c->step_fresh = true;   /* the first advance_rows of the step clears max_reach on ITS stream */
     if (c->wind_grid_on) {
         HIPCHK(c, hipSetDevice(c->device));
@@ -1022,7 +1158,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     long long nt = (long long)(n0 + n1) * G.Nx;
     if (nt == 0) return 0;
     if (c->step_fresh) {   /* max_reach is a per-step quantity */
-        HIPCHK(c, hipMemsetAsync(c->A.max_reach, 0, sizeof(int), s));
+        HIPCHK(c, hipMemsetAsync(c->mr_buf[c->cur], 0, sizeof(int), s));
         c->step_fresh = false;
     }
     timing_begin(c, s, 0);
@@ -1030,7 +1166,8 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
         const KParams &P = c->P;
         bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
         dim3 grid(nblocks(nt, 256)), block(256);
-#define LAUNCH_ADV(F, S) hipLaunchKernelGGL((k_advance<F, S>), grid, block, 0, s, c->P, c->G, c->A, c->clock, c->step_dt, r0, n0, r1, n1)
+        Arrays A = arrays_for(c, c->cur, c->cur);
+#define LAUNCH_ADV(F, S) hipLaunchKernelGGL((k_advance<F, S>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1)
         if (fast && P.wind_static) LAUNCH_ADV(true, true);
         else if (fast) LAUNCH_ADV(true, false);
         else if (P.wind_static) LAUNCH_ADV(false, true);
@@ -1048,6 +1185,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
 
 static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh)
 {
+    Arrays A = arrays_for(c, c->cur, c->cur);
     int flags = c->step_flags;
     bool movie = (flags & PICLES_STEP_MOVIE) != 0;
     bool zero_first = (flags & PICLES_STEP_ZERO_FIRST) != 0;
@@ -1057,7 +1195,7 @@ static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh)
         if (!accum) HIPCHK(c, hipMemsetAsync(c->A.state, 0, 3 * c->A.n * 8, s));
         int ntx = (c->G.Nx + PT_TX - 1) / PT_TX, nty = (c->G.ny_loc + PT_TY - 1) / PT_TY;
         timing_begin(c, s, 1);
-        hipLaunchKernelGGL(k_push_tiles<true>, dim3(ntx * nty), dim3(256), 0, s, c->G, c->A, ntx,
+        hipLaunchKernelGGL(k_push_tiles<true>, dim3(ntx * nty), dim3(256), 0, s, c->G, A, ntx,
                            (const int *)nullptr, (const int *)nullptr, (const int *)nullptr,
                            (const double *)nullptr, (const double *)nullptr, 0LL);
         timing_end(c, s);
@@ -1065,7 +1203,7 @@ static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh)
         if (movie) HIPCHK(c, hipMemcpyAsync(c->A.movie, c->A.state, 3 * c->A.n * 8, hipMemcpyDeviceToDevice, s));
         if (remesh) {
             timing_begin(c, s, 2);
-            hipLaunchKernelGGL(k_remesh, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, c->A, c->clock, c->step_dt);
+            hipLaunchKernelGGL(k_remesh, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, A, c->clock, c->step_dt);
             timing_end(c, s);
             HIPCHK(c, hipGetLastError());
         }
@@ -1075,9 +1213,9 @@ static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh)
     }
     timing_begin(c, s, 1);
     if (remesh)
-        hipLaunchKernelGGL(k_scatter<true>, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, c->A, accum, movie ? 1 : 0, c->clock, c->step_dt);
+        hipLaunchKernelGGL(k_scatter<true>, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, A, accum, movie ? 1 : 0, c->clock, c->step_dt);
     else
-        hipLaunchKernelGGL(k_scatter<false>, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, c->A, accum, 0, c->clock, c->step_dt);
+        hipLaunchKernelGGL(k_scatter<false>, dim3(nblocks(c->A.n, 256)), dim3(256), 0, s, c->P, c->G, A, accum, 0, c->clock, c->step_dt);
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
     c->state_zero = movie && remesh;
@@ -1100,6 +1238,40 @@ PX_EXPORT int32_t picles_time_step(picles_ctx *c, double dt, int32_t flags)
 {
     if (!c) return -1;
     if (!c->G.single_slab) return fail(c, -5, "picles_time_step needs the whole grid; slabs use begin_step/advance_rows/scatter_remesh");
+    if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
+    const KParams &P = c->P;
+    bool fusable = (flags == PICLES_STEP_ZERO_FIRST) && P.wind_static && !c->wind_grid_on && c->fuse_steps;
+    if (fusable) {
+        /* run!-style consecutive steps: one launch per step (k_step), the scatter + remesh of the
+         * previous step ride along; the last one is flushed when somebody looks */
+        HIPCHK(c, hipSetDevice(c->device));
+        if (!c->pending) {
+            int rc0 = picles_begin_step(c, dt, flags);
+            if (rc0) return rc0;
+            rc0 = picles_advance_rows(c, PICLES_ROWS_ALL, nullptr);
+            if (rc0) return rc0;
+        } else {
+            int prev = c->cur;
+            c->cur ^= 1;
+            HIPCHK(c, hipMemsetAsync(c->mr_buf[c->cur], 0, sizeof(int), c->stream));
+            Arrays A = arrays_for(c, prev, c->cur);
+            bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+            dim3 grid(nblocks(c->A.n, 256)), block(256);
+            timing_begin(c, c->stream, 0);
+            if (fast) hipLaunchKernelGGL((k_step<true>), grid, block, 0, c->stream, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, dt);
+            else hipLaunchKernelGGL((k_step<false>), grid, block, 0, c->stream, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, dt);
+            timing_end(c, c->stream);
+            HIPCHK(c, hipGetLastError());
+            c->step_dt = dt;
+            c->step_flags = flags;
+        }
+        c->pending = true;
+        c->pend_t = c->clock;
+        c->pend_dt = dt;
+        c->state_zero = false;
+        c->clock += dt;
+        return 0;
+    }
     int rc = picles_begin_step(c, dt, flags);
     if (rc) return rc;
     rc = picles_advance_rows(c, PICLES_ROWS_ALL, nullptr);
@@ -1122,8 +1294,9 @@ PX_EXPORT int32_t picles_remesh(picles_ctx *c, double dt)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     timing_begin(c, c->stream, 2);
-    hipLaunchKernelGGL(k_remesh, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, c->A, c->clock, dt);
+    hipLaunchKernelGGL(k_remesh, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, arrays_for(c, c->cur, c->cur), c->clock, dt);
     timing_end(c, c->stream);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1133,6 +1306,7 @@ PX_EXPORT int32_t picles_remesh(picles_ctx *c, double dt)
 static int d2h(picles_ctx *c, void *dst, const void *src, size_t bytes)
 {
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());   /* kernels may have run on caller-provided streams */
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1141,6 +1315,7 @@ static int d2h(picles_ctx *c, void *dst, const void *src, size_t bytes)
 static int h2d(picles_ctx *c, void *dst, const void *src, size_t bytes)
 {
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1188,7 +1363,7 @@ PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
     int rc = d2h(c, d.data(), c->A.cnt, NSLOTS * sizeof(DevCounters));
     if (rc) return rc;
     int mr = 0;
-    if ((rc = d2h(c, &mr, c->A.max_reach, sizeof(int)))) return rc;
+    if ((rc = d2h(c, &mr, c->mr_buf[c->cur], sizeof(int)))) return rc;
     memset(out, 0, sizeof(*out));
     for (const DevCounters &k : d) {
         out->rhs_evals += k.rhs; out->steps_accepted += k.acc; out->steps_rejected += k.rej;
@@ -1203,6 +1378,7 @@ PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
     return 0;
@@ -1211,6 +1387,7 @@ PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
 PX_EXPORT int32_t picles_enable_timing(picles_ctx *c, int32_t on)
 {
     if (!c) return -1;
+    { int rc = flush(c); if (rc) return rc; }
     timing_collect(c);
     c->timing = on != 0;
     if (on) memset(&c->tim, 0, sizeof(c->tim));
@@ -1221,6 +1398,7 @@ PX_EXPORT int32_t picles_get_timing(picles_ctx *c, picles_timing *t)
 {
     if (!c || !t) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     timing_collect(c);
     *t = c->tim;
     return 0;
@@ -1258,6 +1436,7 @@ PX_EXPORT int32_t picles_store_push(picles_ctx *c)
     if (!c->store_slots) return fail(c, -2, "picles_store_init first");
     if (c->store_count == c->store_slots) return fail(c, -3, "snapshot ring full: pop first");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     int slot = (c->store_head + c->store_count) % c->store_slots;
     size_t b = 3 * (size_t)c->A.n * 8;
     /* stream-ordered behind the step that produced State; the D2H leg runs beside the next steps */
@@ -1295,19 +1474,23 @@ PX_EXPORT int32_t picles_set_halo_rows(picles_ctx *c, int32_t r)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->G.single_slab && ((c->G.periodic_x && c->G.Nx <= 2 * r) || (c->G.periodic_y && c->G.Ny <= 2 * r)))
         return fail(c, -2, "periodic axis shorter than 2*halo_rows+1");
+    { int rc = flush(c); if (rc) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     /* keep the records of the own rows: re-pack into the new ghost-row geometry */
     int oldR = c->G.R;
     size_t row_b = (size_t)6 * c->G.Nx * 8;
-    double *old = c->A.rec;
-    c->A.rec = nullptr;
     c->G.R = r;
     c->G.Rp = c->G.single_slab ? 0 : r;
-    HIPCHK(c, hipMalloc(&c->A.rec, rec_bytes(c)));
-    HIPCHK(c, hipMemsetAsync(c->A.rec, 0, rec_bytes(c), c->stream));
-    HIPCHK(c, hipMemcpyAsync((char *)c->A.rec + (size_t)r * row_b, (char *)old + (size_t)oldR * row_b,
-                             (size_t)c->G.ny_loc * row_b, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(old));
+    for (int k = 0; k < 2; k++) {
+        double *old = c->rec_buf[k];
+        c->rec_buf[k] = nullptr;
+        HIPCHK(c, hipMalloc(&c->rec_buf[k], rec_bytes(c)));
+        HIPCHK(c, hipMemsetAsync(c->rec_buf[k], 0, rec_bytes(c), c->stream));
+        HIPCHK(c, hipMemcpyAsync((char *)c->rec_buf[k] + (size_t)r * row_b, (char *)old + (size_t)oldR * row_b,
+                                 (size_t)c->G.ny_loc * row_b, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(old));
+    }
     return 0;
 }
 
@@ -1320,7 +1503,7 @@ static int halo_ptr(picles_ctx *c, int side, bool send, void **ptr, size_t *byte
     int row;
     if (send) row = (side == 0) ? G.R : G.ny_loc;          /* own first R rows / own last R rows */
     else row = (side == 0) ? 0 : G.ny_loc + G.R;            /* ghost rows below / above */
-    *ptr = (char *)c->A.rec + (size_t)row * row_b;
+    *ptr = (char *)c->rec_buf[c->cur] + (size_t)row * row_b;   /* the step in flight (after picles_begin_step) */
     *bytes = (size_t)G.R * row_b;
     return 0;
 }
@@ -1335,6 +1518,7 @@ PX_EXPORT int32_t picles_scatter_particles(picles_ctx *c, int64_t np, const int3
     if (np == 0) return 0;
     if (np > 0x7fffffffLL) return fail(c, -2, "too many particles for one call");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
     hipStream_t s = c->stream;
     int ntx = (c->G.Nx + PT_TX - 1) / PT_TX, nty = (c->G.ny_loc + PT_TY - 1) / PT_TY;
     int ntiles = ntx * nty;
@@ -1358,7 +1542,7 @@ PX_EXPORT int32_t picles_scatter_particles(picles_ctx *c, int64_t np, const int3
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->d_scan_tmp, c->scan_tmp_bytes, c->d_count, c->d_start, ntiles + 1, s));
     hipLaunchKernelGGL(k_tile_fill, dim3(nblocks(np, 256)), dim3(256), 0, s, (long long)np, d_tile, c->d_start, c->d_cursor, d_perm);
     timing_begin(c, s, 1);
-    hipLaunchKernelGGL(k_push_tiles<false>, dim3(ntiles), dim3(256), 0, s, c->G, c->A, ntx, c->d_start, d_perm, d_ij, d_xy, d_ch, (long long)np);
+    hipLaunchKernelGGL(k_push_tiles<false>, dim3(ntiles), dim3(256), 0, s, c->G, arrays_for(c, c->cur, c->cur), ntx, c->d_start, d_perm, d_ij, d_xy, d_ch, (long long)np);
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));

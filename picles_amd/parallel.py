@@ -59,24 +59,32 @@ class HaloExchange:
         self._bind()
 
     def _bind(self):
+        """(re)query the halo blocks of the step in flight.  The library double-buffers its record
+        array, so the four pointers alternate between two sets: tensors are cached per pointer."""
         torch = self.torch
-        self.blocks = {}
-        for name, fn in (("send_lo", lambda: self.backend.halo_send(0)), ("send_hi", lambda: self.backend.halo_send(1)),
-                         ("recv_lo", lambda: self.backend.halo_recv(0)), ("recv_hi", lambda: self.backend.halo_recv(1))):
-            ptr, nbytes = fn()
-            self.blocks[name] = (ptr, nbytes)
+        self.blocks = {"send_lo": self.backend.halo_send(0), "send_hi": self.backend.halo_send(1),
+                       "recv_lo": self.backend.halo_recv(0), "recv_hi": self.backend.halo_recv(1)}
         if self.staged:
             n = self.blocks["send_lo"][1] // 8
-            self.host = {k: torch.empty(n, dtype=torch.float64) for k in self.blocks}
-            if self.host_blocks:
-                self._copy = lambda dst, src, n, kind: (C.memmove(dst, src, n), 0)[1]
-            else:
-                hip = C.CDLL("libamdhip64.so")
-                hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-                hip.hipMemcpy.restype = C.c_int
-                self._copy = hip.hipMemcpy
+            if not hasattr(self, "host") or self.host["send_lo"].numel() != n:
+                self.host = {k: torch.empty(n, dtype=torch.float64) for k in self.blocks}
+            if not hasattr(self, "_copy"):
+                if self.host_blocks:
+                    self._copy = lambda dst, src, n, kind: (C.memmove(dst, src, n), 0)[1]
+                else:
+                    hip = C.CDLL("libamdhip64.so")
+                    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                    hip.hipMemcpy.restype = C.c_int
+                    self._copy = hip.hipMemcpy
         else:
-            self.dev = {k: torch.as_tensor(_DevBlock(p, n), device="cuda") for k, (p, n) in self.blocks.items()}
+            if not hasattr(self, "_views"):
+                self._views = {}
+            self.dev = {}
+            for k, (p, n) in self.blocks.items():
+                key = (p, n)
+                if key not in self._views:
+                    self._views[key] = torch.as_tensor(_DevBlock(p, n), device="cuda")
+                self.dev[k] = self._views[key]
 
     def rebind(self):
         self._bind()
@@ -85,6 +93,7 @@ class HaloExchange:
         """post the sends/recvs; returns the work handles (call inside the edge stream context)"""
         if self.world == 1 or (self.prev is None and self.next is None):
             return []
+        self._bind()
         dist = self.dist
         if self.staged:
             if not self.host_blocks:
