@@ -67,6 +67,21 @@ def cpu_baseline(args, W, K):
                       f"(C oracle: OpenMP advance + node-parallel pull scatter, {threads} threads on {cores} host cores)"}
 
 
+def measured_traffic(args, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled: profiles/*_pmc_summary.md) — only when
+    the profile was taken on this exact workload; PMC counters cannot be read live in a timed run."""
+    f = ROOT / "profiles" / "r1_pmc_traffic.json"
+    try:
+        d = json.loads(f.read_text())
+        if world == 1 and d["config"]["n"] == args.n and tuple(d["config"]["winds"]) == tuple(args.winds):
+            k = d["kernels"][d["dominant"]]
+            return k["hbm_read_bytes"] + k["hbm_write_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,13 +188,13 @@ def main():
             },
             "hbm_GBps_path": B_ALG * value / 1e9,
             "roofline": {
-                "kernel": "k_advance",
+                "kernel": "k_step (fused scatter+remesh+advance; k_advance + k_scatter for slabs)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic(args, world),
                 "avg_launch_ms": adv_ms,
                 "note": "the fused RK advance is fp64-VALU bound, not HBM bound (DESIGN.md): see fp64",
             },
@@ -190,7 +205,7 @@ def main():
                 "peak_tflops": FP64_PEAK_TFLOPS * world,
                 "frac": tflops / (FP64_PEAK_TFLOPS * world),
             },
-            "kernel_ms_per_step": {"advance": tim["advance_ms"] / Ksteps, "scatter_remesh": tim["scatter_ms"] / Ksteps,
+            "kernel_ms_per_step": {"step_or_advance": tim["advance_ms"] / Ksteps, "scatter_remesh": tim["scatter_ms"] / Ksteps,
                                    "remesh": tim["remesh_ms"] / Ksteps},
         }
         if world == 1 and not args.no_cpu:
