@@ -126,6 +126,12 @@ int32_t picles_abi_version(void);
 int32_t picles_set_winds(picles_ctx *ctx, const double *u0, const double *v0, double t0,
                          const double *u1, const double *v1, double t1);
 
+/* Non-Cartesian meshes (SphericalGrid.jl:207-240, spherical_grid_corrections.jl:3-21): per-node
+ * projection kernel M = diag(m11, m22) of the propagation terms (particle_waves_v5.jl:536) and the
+ * great-circle coefficient of PropagationCorrection, S_sphere = c̄_x * pc (:521-530); own rows,
+ * col-major.  NULL pointers restore the Cartesian constants M = diag(1/dx, 1/dy), pc = 0. */
+int32_t picles_set_metric(picles_ctx *ctx, const double *m11, const double *m22, const double *pc);
+
 /* Gridded wind forcing (Utils/WindEmulator.jl:18-43 wind_interpolator =
  * Interpolations.linear_interpolation((x,y,t), u; extrapolation_bc = Periodic())): u,v on a regular
  * (x,y,t) lattice [nx*ny*nt], x fastest.  The library keeps the lattice in HBM and samples the two

@@ -117,6 +117,7 @@ typedef struct po_model {
     int64_t n_step;
     int64_t *steplist;         /* ocean_points in reference order */
     double *u0, *v0, *u1, *v1;
+    double *m11, *m22, *pc;    /* per-node projection M = diag(m11, m22) and great-circle coefficient (NULL: Cartesian) */
     double tw0, tw1;
     int wind_static;
     double clock;
@@ -209,7 +210,7 @@ static void po_charge_to_particle(const double c[3], double z[5])
 /* ------------------------------------------------------------------------------------------
  * RHS — particle_system(dz,z,params,t), particle_waves_v5.jl:479-556 (Cartesian: PC ≡ 0)
  * ---------------------------------------------------------------------------------------- */
-static void po_rhs_literal(const po_model *M, const double z[5], double u, double v, double dz[5])
+static void po_rhs_literal(const po_model *M, int64_t idx, const double z[5], double u, double v, double dz[5])
 {
     const picles_phys *ph = &M->ph;
     const po_consts *k = &M->k;
@@ -259,11 +260,19 @@ static void po_rhs_literal(const po_model *M, const double z[5], double u, doubl
         Sd = a2 * a2 * ph->C_phi * H * s2;
     }
     dz[0] = wp * r_g * Scg + wp * (It - Dt);               /* :526 */
-    dz[1] = -cx * wp * r_g * Scg + cy * Sd;                /* :529 */
-    dz[2] = -cy * wp * r_g * Scg - cx * Sd;                /* :530 */
-    if (ph->propagation) {                                 /* :536, M = diag(1/dx,1/dy) */
-        dz[3] = k->inv_dx * cx;
-        dz[4] = k->inv_dy * cy;
+    if (M->pc) {
+        /* S_sphere_tilde = PropagationCorrection(c̄_x) = c̄_x * coefficient (:521-530,
+         * spherical_grid_corrections.jl:3-21) */
+        double Ss = cx * M->pc[idx];
+        dz[1] = -cx * wp * r_g * Scg + cy * Sd + cy * Ss;
+        dz[2] = -cy * wp * r_g * Scg - cx * Sd - cx * Ss;
+    } else {
+        dz[1] = -cx * wp * r_g * Scg + cy * Sd;            /* :529 (PC ≡ 0 on the Cartesian mesh) */
+        dz[2] = -cy * wp * r_g * Scg - cx * Sd;            /* :530 */
+    }
+    if (ph->propagation) {                                 /* :536, M*[c̄x,c̄y]; M = diag(1/dx,1/dy) or per node */
+        dz[3] = (M->m11 ? M->m11[idx] : k->inv_dx) * cx;
+        dz[4] = (M->m22 ? M->m22[idx] : k->inv_dy) * cy;
     } else {
         dz[3] = 0.0;
         dz[4] = 0.0;
@@ -275,7 +284,7 @@ static void po_rhs_literal(const po_model *M, const double z[5], double u, doubl
  * exact arithmetic); sin 2(θ_c-θ_w) is evaluated as 2·cross·dot/(U|g|)² (algebraically equal to
  * sin2_a_min_b :242-249, exactly zero for aligned vectors); H_β via the logistic function,
  * sech² via one exp; fused multiply-adds written out. */
-static void po_rhs_kernel(const po_model *M, const double z[5], double u, double v, double dz[5])
+static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], double u, double v, double dz[5])
 {
     const picles_phys *ph = &M->ph;
     const po_consts *k = &M->k;
@@ -330,22 +339,23 @@ static void po_rhs_kernel(const po_model *M, const double z[5], double u, double
         Sd = (((alpha * alpha) * ph->C_phi) * H) * s2;
     }
     double wrS = (wp * ph->r_g) * Scg;
+    if (M->pc) Sd = Sd + cx * M->pc[idx];   /* great-circle term rides on the direction term */
     dz[0] = PO_FMA(wp, It - Dt, wrS);
     dz[1] = PO_FMA(cy, Sd, -(cx * wrS));
     dz[2] = -PO_FMA(cx, Sd, cy * wrS);
     if (ph->propagation) {
-        dz[3] = cx * k->inv_dx;
-        dz[4] = cy * k->inv_dy;
+        dz[3] = cx * (M->m11 ? M->m11[idx] : k->inv_dx);
+        dz[4] = cy * (M->m22 ? M->m22[idx] : k->inv_dy);
     } else {
         dz[3] = 0.0;
         dz[4] = 0.0;
     }
 }
 
-static inline void po_rhs(const po_model *M, const double z[5], double u, double v, double dz[5])
+static inline void po_rhs(const po_model *M, int64_t idx, const double z[5], double u, double v, double dz[5])
 {
-    if (M->order == 0) po_rhs_literal(M, z, u, v, dz);
-    else po_rhs_kernel(M, z, u, v, dz);
+    if (M->order == 0) po_rhs_literal(M, idx, z, u, v, dz);
+    else po_rhs_kernel(M, idx, z, u, v, dz);
 }
 
 /* node wind at absolute time t: the boundary's replacement of the closures u(x,y,t), v(x,y,t)
@@ -414,7 +424,7 @@ static double po_initdt(const po_model *M, int64_t idx, const double u0[5], cons
     double u1[5], f1[5], uw, vw;
     for (int i = 0; i < 5; i++) u1[i] = K ? PO_FMA(dt0, f0[i], u0[i]) : u0[i] + dt0 * f0[i];
     po_wind(M, idx, t + dt0, &uw, &vw);
-    po_rhs(M, u1, uw, vw, f1);
+    po_rhs(M, idx, u1, uw, vw, f1);
     st->rhs++;
     for (int i = 0; i < 5; i++) a1[i] = (f1[i] - f0[i]) / sk[i];
     double d2 = (K ? po_norm5_k(a1) : po_norm5_lit(a1)) / dt0;
@@ -449,27 +459,27 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
         for (int i = 0; i < 5; i++) g[i] = PO_FMA(a, k1[i], u0[i]);
     }
     po_wind(M, idx, K ? PO_FMA(C2, h, t) : t + C2 * h, &uw, &vw);
-    po_rhs(M, g, uw, vw, k2);
+    po_rhs(M, idx, g, uw, vw, k2);
     STAGE(u0[i] + h * (A31 * k1[i] + A32 * k2[i]),
           PO_FMA(h, PO_FMA(A32, k2[i], A31 * k1[i]), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C3, h, t) : t + C3 * h, &uw, &vw);
-    po_rhs(M, g, uw, vw, k3);
+    po_rhs(M, idx, g, uw, vw, k3);
     STAGE(u0[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]),
           PO_FMA(h, PO_FMA(A43, k3[i], PO_FMA(A42, k2[i], A41 * k1[i])), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C4, h, t) : t + C4 * h, &uw, &vw);
-    po_rhs(M, g, uw, vw, k4);
+    po_rhs(M, idx, g, uw, vw, k4);
     STAGE(u0[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]),
           PO_FMA(h, PO_FMA(A54, k4[i], PO_FMA(A53, k3[i], PO_FMA(A52, k2[i], A51 * k1[i]))), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C5, h, t) : t + C5 * h, &uw, &vw);
-    po_rhs(M, g, uw, vw, k5);
+    po_rhs(M, idx, g, uw, vw, k5);
     STAGE(u0[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]),
           PO_FMA(h, PO_FMA(A65, k5[i], PO_FMA(A64, k4[i], PO_FMA(A63, k3[i], PO_FMA(A62, k2[i], A61 * k1[i])))), u0[i]));
     po_wind(M, idx, t + h, &uw, &vw);
-    po_rhs(M, g, uw, vw, k6);
+    po_rhs(M, idx, g, uw, vw, k6);
     for (int i = 0; i < 5; i++)
         unew[i] = K ? PO_FMA(h, PO_FMA(A76, k6[i], PO_FMA(A75, k5[i], PO_FMA(A74, k4[i], PO_FMA(A73, k3[i], A71 * k1[i])))), u0[i])
                     : u0[i] + h * (A71 * k1[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
-    po_rhs(M, unew, uw, vw, k7);
+    po_rhs(M, idx, unew, uw, vw, k7);
     st->rhs += 6;
 #undef STAGE
     double at[5];
@@ -495,7 +505,7 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
     double k1[5], k7[5], unew[5], uw, vw;
     double tr = 0.0; /* time since t_start; absolute time = t_start + tr */
     po_wind(M, idx, t_start, &uw, &vw);
-    po_rhs(M, z, uw, vw, k1);
+    po_rhs(M, idx, z, uw, vw, k1);
     st->rhs++;
     double dt = *dtn;
     if (!(dt > 0.0)) dt = po_initdt(M, idx, z, k1, t_start, st);
@@ -761,7 +771,22 @@ PO_EXPORT int32_t picles_oracle_destroy(po_model *M)
     free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->dtn); free(M->grp); free(M->rec);
     free(M->on); free(M->bnd); free(M->status); free(M->steplist);
     free(M->u0); free(M->v0); free(M->u1); free(M->v1);
+    free(M->m11); free(M->m22); free(M->pc);
     free(M);
+    return 0;
+}
+
+/* per-node ProjetionKernel diagonal and PropagationCorrection coefficient (SphericalGrid.jl:207-240,
+ * spherical_grid_corrections.jl:3-21); NULL restores the Cartesian constants */
+PO_EXPORT int32_t picles_oracle_set_metric(po_model *M, const double *m11, const double *m22, const double *pc)
+{
+    free(M->m11); free(M->m22); free(M->pc);
+    M->m11 = M->m22 = M->pc = NULL;
+    if (m11 && m22 && pc) {
+        M->m11 = (double *)malloc(M->N * 8); memcpy(M->m11, m11, M->N * 8);
+        M->m22 = (double *)malloc(M->N * 8); memcpy(M->m22, m22, M->N * 8);
+        M->pc = (double *)malloc(M->N * 8); memcpy(M->pc, pc, M->N * 8);
+    }
     return 0;
 }
 
@@ -1109,7 +1134,7 @@ PO_EXPORT int32_t picles_oracle_time_step_pull(po_model *M, double dt, int32_t f
 
 /* ---- single-function entry points for unit tests ---------------------------------------- */
 PO_EXPORT void picles_oracle_windsea(double U, double V, double T, double out[3]) { po_windsea(U, V, T, out); }
-PO_EXPORT void picles_oracle_rhs(po_model *M, const double z[5], double u, double v, double dz[5]) { po_rhs(M, z, u, v, dz); }
+PO_EXPORT void picles_oracle_rhs(po_model *M, const double z[5], double u, double v, double dz[5]) { po_rhs(M, 0, z, u, v, dz); }
 PO_EXPORT void picles_oracle_particle_to_charge(const double z[5], double c[3]) { po_particle_to_charge(z, c); }
 PO_EXPORT void picles_oracle_charge_to_particle(const double c[3], double z[5]) { po_charge_to_particle(c, z); }
 PO_EXPORT void picles_oracle_index_weight(double zp, int32_t i_node, int64_t idx[2], double w[2]) { po_index_weight(zp, i_node, idx, w); }

@@ -102,6 +102,7 @@ SYMBOLS = {
     "picles_last_error": (C.c_char_p, [_VP]),
     "picles_abi_version": (C.c_int32, []),
     "picles_set_winds": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, C.c_double]),
+    "picles_set_metric": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p]),
     "picles_set_wind_grid": (C.c_int32, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                          C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, C.c_double, C.c_double]),
     "picles_get_winds": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p, c_double_p]),

@@ -10,7 +10,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import fetch_relations as FetchRelations
-from .grids import TwoDCartesianGridMesh
+from .grids import TwoDCartesianGridMesh, TwoDSphericalGridMesh
 from .particle_waves_v5 import ODEParameters, ODESettings, particle_equations, IDConstants, ScgConstants
 
 MINUTES, HOURS, DAYS = 60.0, 3600.0, 86400.0
@@ -121,3 +121,35 @@ def growing_decaying_winds(n=2048, dx=2000.0, U10=10.0, V10=10.0, n_steps=60):
                    periodic_boundary=False, boundary_type="same",
                    minimal_particle=FetchRelations.MinimalParticle(U10, V10, DT), movie=False, winds_static=False),
         Δt=DT, n_steps=n_steps, mode="run")
+
+
+def sphere_aqua(nx=91, ny=61, n_steps=8, with_land=True):
+    """tests/T03_PIC_sphere_aqua.jl:36-175 — lon/lat mesh 0..180° × 0..80° (periodic in lon), Gaussian
+    wind blob (-20, 1) m/s centred at (90°, 40°), Δt = 120 min, fixed default particle, C_φ = c_β,
+    lne_max = log 27, a land block (:71-72)."""
+    U10, V10 = -20.0, 1.0
+    DT = 20 * MINUTES
+    ustd, uc, vc = 20.0, 90.0, 40.0
+
+    def u(x, y, t):
+        return U10 * np.exp(-(x - uc) ** 2 / ustd ** 2) * np.exp(-(y - vc) ** 2 / ustd ** 2)
+
+    def v(x, y, t):
+        return V10 * np.exp(-(x - uc) ** 2 / ustd ** 2) * np.exp(-(y - vc) ** 2 / ustd ** 2)
+    winds = SimpleNamespace(u=u, v=v)
+    mask = np.ones((nx, ny), dtype=bool)
+    if with_land:
+        mask[44 * nx // 91:50 * nx // 91, 44 * ny // 61:] = False
+    grid = TwoDSphericalGridMesh(0.0, 180.0, nx, 0.0, 80.0, ny, mask=mask, periodic_boundary=(True, False))
+    ODEpars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
+    psys = particle_equations(u, v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
+    pars = dict(r_g=ODEpars["r_g"], C_α=Const_Scg.C_alpha, C_φ=Const_ID.c_β, C_e=Const_ID.C_e, g=9.81)
+    ws = FetchRelations.MinimalWindsea(U10, V10, DT)
+    from .core_2D import ParticleDefaults
+    sets = ODESettings(Parameters=pars, log_energy_minimum=math.log(ws["E"]), log_energy_maximum=math.log(27),
+                       saving_step=DT, timestep=DT, total_time=6 * DAYS, adaptive=True, dt=1e-3, dtmin=1e-4, force_dtmin=True)
+    return SimpleNamespace(
+        model=dict(grid=grid, winds=winds, ODEsys=psys, ODEsets=sets,
+                   ODEinit_type=ParticleDefaults(math.log(ws["E"]), ws["cg_bar_x"], ws["cg_bar_y"], 0.0, 0.0),
+                   periodic_boundary=False, boundary_type="same", movie=True, winds_static=True),
+        Δt=120 * MINUTES, n_steps=n_steps, mode="run")

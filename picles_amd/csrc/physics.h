@@ -247,8 +247,8 @@ struct Vec3 {
     double lne, cx, cy;
 };
 
-template <bool FAST>
-PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD &W, Vec3 &d)
+template <bool FAST, bool METRIC = false>
+PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD &W, Vec3 &d, double pc = 0.0)
 {
     const double u = W.u, v = W.v;
     double c2 = PM_FMA(cx, cx, cy * cy);
@@ -302,6 +302,7 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
         Sd = (((alpha * alpha) * P.C_phi) * H) * s2;
     }
     double wrS = (wp * P.r_g) * Scg;
+    if (METRIC) Sd = Sd + cx * pc;   /* great-circle term S_sphere = PC(c̄x) = c̄x·coef rides on S_dir */
     d.lne = PM_FMA(wp, It - Dt, wrS);
     d.cx = PM_FMA(cy, Sd, -(cx * wrS));
     d.cy = -PM_FMA(cx, Sd, cy * wrS);
@@ -319,9 +320,9 @@ PM_HD double rms5(double a0, double a1, double a2, double a3, double a4)
 
 /* ode_determine_initdt (Hairer–Wanner), = auto_dt_reset! after every remesh.
  * f0 = (k1, kx, ky) is the RHS at (u0, t). */
-template <bool FAST, bool STATIC>
+template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, const Vec3 &k1, double kx, double ky,
-                     double ipx, double ipy, double t, PStats &st)
+                     double ipx, double ipy, double pc, double t, PStats &st)
 {
     double sk0 = PM_FMA(pm_fabs(u0.lne), P.reltol, P.abstol);
     double sk1 = PM_FMA(pm_fabs(u0.cx), P.reltol, P.abstol);
@@ -337,7 +338,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
     double l1 = PM_FMA(dt0, k1.lne, u0.lne), cx1 = PM_FMA(dt0, k1.cx, u0.cx), cy1 = PM_FMA(dt0, k1.cy, u0.cy);
     Vec3 f1;
     wind_stage<STATIC>(P, w, t + dt0, W);
-    rhs3<FAST>(P, l1, cx1, cy1, W, f1);
+    rhs3<FAST, METRIC>(P, l1, cx1, cy1, W, f1, pc);
     st.rhs++;
     double f1x = cx1 * ipx, f1y = cy1 * ipy;
     double d2 = rms5((f1.lne - k1.lne) / sk0, (f1.cx - k1.cx) / sk1, (f1.cy - k1.cy) / sk2,
@@ -360,12 +361,13 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
 /* step!(integrator, DT, true): integrate z over [t_start, t_start+DT] with DP5(4).
  * Only the stage derivatives of (lne, c̄x, c̄y) are kept; the x,y rows of the tableau are
  * accumulated as the stages appear (same fma order as the full Butcher sums). */
-template <bool FAST, bool STATIC>
+template <bool FAST, bool STATIC, bool METRIC = false>
 PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, double &dtn,
-                         double t_start, double DT, PStats &st)
+                         double t_start, double DT, PStats &st, double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
 {
-    const double ipx = (FAST || P.propagation) ? P.inv_dx : 0.0;
-    const double ipy = (FAST || P.propagation) ? P.inv_dy : 0.0;
+    /* projection M = diag(ipx, ipy): 1/Δx, 1/Δy on the Cartesian mesh, per node otherwise */
+    const double ipx = (FAST || P.propagation) ? (METRIC ? m11 : P.inv_dx) : 0.0;
+    const double ipy = (FAST || P.propagation) ? (METRIC ? m22 : P.inv_dy) : 0.0;
     Vec3 k1, k2, k3, k4, k5, k6, k7;
     WindD W;
     DPTab T;
@@ -373,10 +375,10 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     double tr = 0.0;
     if (STATIC) wind_derive(w.u0, w.v0, W);
     else wind_stage<false>(P, w, t_start, W);
-    rhs3<FAST>(P, z.lne, z.cx, z.cy, W, k1);
+    rhs3<FAST, METRIC>(P, z.lne, z.cx, z.cy, W, k1, pc);
     st.rhs++;
     double dt = dtn;
-    if (!(dt > 0.0)) dt = init_dt<FAST, STATIC>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, t_start, st);
+    if (!(dt > 0.0)) dt = init_dt<FAST, STATIC, METRIC>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, pc, t_start, st);
     long long iter = 0;
     while (tr < DT) {
         iter++;
@@ -397,32 +399,32 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
         }
         wind_stage<STATIC>(P, w, PM_FMA(T.c2, h, t), W);
-        rhs3<FAST>(P, gl, gx, gy, W, k2);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k2, pc);
 #define ST3(c) PM_FMA(h, PM_FMA(T.a32, k2.c, T.a31 * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
         wind_stage<STATIC>(P, w, PM_FMA(T.c3, h, t), W);
-        rhs3<FAST>(P, gl, gx, gy, W, k3);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k3, pc);
         kx = gx * ipx; ky = gy * ipy;
         ax = PM_FMA(T.a73, kx, ax); ay = PM_FMA(T.a73, ky, ay);
         ex = PM_FMA(T.e3, kx, ex); ey = PM_FMA(T.e3, ky, ey);
 #define ST4(c) PM_FMA(h, PM_FMA(T.a43, k3.c, PM_FMA(T.a42, k2.c, T.a41 * k1.c)), z.c)
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
         wind_stage<STATIC>(P, w, PM_FMA(T.c4, h, t), W);
-        rhs3<FAST>(P, gl, gx, gy, W, k4);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k4, pc);
         kx = gx * ipx; ky = gy * ipy;
         ax = PM_FMA(T.a74, kx, ax); ay = PM_FMA(T.a74, ky, ay);
         ex = PM_FMA(T.e4, kx, ex); ey = PM_FMA(T.e4, ky, ey);
 #define ST5(c) PM_FMA(h, PM_FMA(T.a54, k4.c, PM_FMA(T.a53, k3.c, PM_FMA(T.a52, k2.c, T.a51 * k1.c))), z.c)
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
         wind_stage<STATIC>(P, w, PM_FMA(T.c5, h, t), W);
-        rhs3<FAST>(P, gl, gx, gy, W, k5);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k5, pc);
         kx = gx * ipx; ky = gy * ipy;
         ax = PM_FMA(T.a75, kx, ax); ay = PM_FMA(T.a75, ky, ay);
         ex = PM_FMA(T.e5, kx, ex); ey = PM_FMA(T.e5, ky, ey);
 #define ST6(c) PM_FMA(h, PM_FMA(T.a65, k5.c, PM_FMA(T.a64, k4.c, PM_FMA(T.a63, k3.c, PM_FMA(T.a62, k2.c, T.a61 * k1.c)))), z.c)
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
-        rhs3<FAST>(P, gl, gx, gy, W, k6);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k6, pc);
         kx = gx * ipx; ky = gy * ipy;
         ax = PM_FMA(T.a76, kx, ax); ay = PM_FMA(T.a76, ky, ay);
         ex = PM_FMA(T.e6, kx, ex); ey = PM_FMA(T.e6, ky, ey);
@@ -430,7 +432,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         Vec5 un;
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax, z.x); un.y = PM_FMA(h, ay, z.y);
-        rhs3<FAST>(P, un.lne, un.cx, un.cy, W, k7);
+        rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, k7, pc);
         st.rhs += 6;
         kx = un.cx * ipx; ky = un.cy * ipy;
         ex = PM_FMA(T.e7, kx, ex); ey = PM_FMA(T.e7, ky, ey);

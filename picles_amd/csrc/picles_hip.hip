@@ -69,6 +69,7 @@ struct Arrays {
     unsigned char *on, *pflags;
     int *status;
     double *u0, *v0, *u1, *v1;
+    double *m11, *m22, *pc;  /* per-node projection diag and great-circle coefficient (NULL: Cartesian) */
     double *rec;             /* records the scatter reads  (latest completed advance) */
     double *rec_out;         /* records the advance writes (the other buffer of the pair) */
     DevCounters *cnt;        /* [NSLOTS] */
@@ -190,14 +191,15 @@ struct StepStats {
     int reach;
 };
 
-template <bool FAST, bool STATIC>
+template <bool FAST, bool STATIC, bool METRIC = false>
 __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
-                                                double &dtn, double t_start, double DT, StepStats &S)
+                                                double &dtn, double t_start, double DT, StepStats &S,
+                                                double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
 {
     int status = PICLES_ST_STEPPED;
     if (on) {
         S.adv = 1;
-        integrate_dp5<FAST, STATIC>(P, w, z, qold, dtn, t_start, DT, S.st);
+        integrate_dp5<FAST, STATIC, METRIC>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc);
         status |= S.st.status;
     } else {
         double u, v;
@@ -296,7 +298,7 @@ __device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r
  * adaptive RK loop runs in registers.  Writes the particle's scatter record instead of
  * scattering: the scatter itself is k_scatter / k_step / k_push_tiles.
  * ---------------------------------------------------------------------------------------- */
-template <bool FAST, bool STATIC>
+template <bool FAST, bool STATIC, bool METRIC>
 __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
                                                    int r0, int n0, int r1, int n1)
 {
@@ -314,7 +316,9 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         int on = A.on[t];
         double qold = A.qold[t], dtn = A.dtn[t];
         Wind w = load_wind(P, A, t);
-        int status = advance_particle<FAST, STATIC>(P, w, z, on, qold, dtn, t_start, DT, S);
+        int status;
+        if (METRIC) status = advance_particle<FAST, STATIC, true>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t]);
+        else status = advance_particle<FAST, STATIC, false>(P, w, z, on, qold, dtn, t_start, DT, S);
         A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
         A.on[t] = (unsigned char)on;
         A.qold[t] = qold;
@@ -958,6 +962,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     hipFree(A.cnt); hipFree(c->d_mask);
+    if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
     for (int k = 0; k < 2; k++) { hipFree(c->rec_buf[k]); hipFree(c->mr_buf[k]); }
     for (auto p : c->store_dev) hipFree(p);
     for (auto p : c->store_host) hipHostFree(p);
@@ -1016,6 +1021,24 @@ PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double
 }
 
 static inline unsigned nblocks(long long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+/* per-node ProjetionKernel diagonal + PropagationCorrection coefficient */
+PX_EXPORT int32_t picles_set_metric(picles_ctx *c, const double *m11, const double *m22, const double *pc)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
+    HIPCHK(c, hipDeviceSynchronize());
+    Arrays &A = c->A;
+    if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); A.m11 = A.m22 = A.pc = nullptr; }
+    if (!m11 || !m22 || !pc) return 0;   /* back to the Cartesian constants */
+    size_t b = (size_t)A.n * 8;
+    HIPCHK(c, hipMalloc(&A.m11, b)); HIPCHK(c, hipMalloc(&A.m22, b)); HIPCHK(c, hipMalloc(&A.pc, b));
+    HIPCHK(c, hipMemcpy(A.m11, m11, b, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(A.m22, m22, b, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(A.pc, pc, b, hipMemcpyHostToDevice));
+    return 0;
+}
 
 PX_EXPORT int32_t picles_set_wind_grid(picles_ctx *c, int32_t nx, int32_t ny, int32_t nt,
                                        double x0, double dx, double y0, double dy, double t0, double dt,
@@ -1167,11 +1190,12 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
         bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
         dim3 grid(nblocks(nt, 256)), block(256);
         Arrays A = arrays_for(c, c->cur, c->cur);
-#define LAUNCH_ADV(F, S) hipLaunchKernelGGL((k_advance<F, S>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1)
-        if (fast && P.wind_static) LAUNCH_ADV(true, true);
-        else if (fast) LAUNCH_ADV(true, false);
-        else if (P.wind_static) LAUNCH_ADV(false, true);
-        else LAUNCH_ADV(false, false);
+#define LAUNCH_ADV(F, S, M) hipLaunchKernelGGL((k_advance<F, S, M>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1)
+        if (c->A.pc) LAUNCH_ADV(false, false, true);   /* per-node metric: the general code path */
+        else if (fast && P.wind_static) LAUNCH_ADV(true, true, false);
+        else if (fast) LAUNCH_ADV(true, false, false);
+        else if (P.wind_static) LAUNCH_ADV(false, true, false);
+        else LAUNCH_ADV(false, false, false);
 #undef LAUNCH_ADV
     }
     timing_end(c, s);
@@ -1240,7 +1264,7 @@ PX_EXPORT int32_t picles_time_step(picles_ctx *c, double dt, int32_t flags)
     if (!c->G.single_slab) return fail(c, -5, "picles_time_step needs the whole grid; slabs use begin_step/advance_rows/scatter_remesh");
     if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
     const KParams &P = c->P;
-    bool fusable = (flags == PICLES_STEP_ZERO_FIRST) && P.wind_static && !c->wind_grid_on && c->fuse_steps;
+    bool fusable = (flags == PICLES_STEP_ZERO_FIRST) && P.wind_static && !c->wind_grid_on && c->fuse_steps && !c->A.pc;
     if (fusable) {
         /* run!-style consecutive steps: one launch per step (k_step), the scatter + remesh of the
          * previous step ride along; the last one is flushed when somebody looks */

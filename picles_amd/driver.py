@@ -71,6 +71,11 @@ class HipModel:
         self._ck(self.lib.picles_set_winds(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(u1), K.dptr(v1), t1),
                  "picles_set_winds")
 
+    def set_metric(self, m11, m22, pc):
+        """per-node projection diag(m11, m22) and great-circle coefficient (picles_set_metric)"""
+        a = [_col(x, self.N) for x in (m11, m22, pc)]
+        self._ck(self.lib.picles_set_metric(self.h, K.dptr(a[0]), K.dptr(a[1]), K.dptr(a[2])), "picles_set_metric")
+
     def set_wind_grid(self, lat: dict, mesh_x0: float, mesh_y0: float):
         """upload an (x,y,t) wind lattice; the device samples it every step (picles_set_wind_grid)"""
         self._wg = (lat["u"], lat["v"])

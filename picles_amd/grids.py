@@ -104,3 +104,83 @@ class TwoDCartesianGridMesh:
     def ProjetionKernel(self):
         """CartesianGrid.jl:115-121"""
         return np.array([[1 / self.stats.dx, 0.0], [0.0, 1 / self.stats.dy]])
+
+
+# ---------------------------------------------------------------------------------------------
+# Spherical (lon/lat) mesh — reference: src/Grids/SphericalGrid.jl, spherical_grid_corrections.jl
+# ---------------------------------------------------------------------------------------------
+R_EARTH_MESH = 6371.0e3      # SphericalGrid.jl:54,72
+R_EARTH_PC = 6.3710e6        # spherical_grid_corrections.jl:3
+
+
+def cal_dx_degree(XX):
+    """SphericalGrid.jl:25-31: centred differences, one-sided at the ends"""
+    dx = np.zeros(XX.shape)
+    dx[1:-1, :] = (XX[2:, :] - XX[:-2, :]) / 2
+    dx[0, :] = XX[1, :] - XX[0, :]
+    dx[-1, :] = XX[-1, :] - XX[-2, :]
+    return dx
+
+
+def cal_dy_degree(YY):
+    """SphericalGrid.jl:33-39"""
+    dy = np.zeros(YY.shape)
+    dy[:, 1:-1] = (YY[:, 2:] - YY[:, :-2]) / 2
+    dy[:, 0] = YY[:, 1] - YY[:, 0]
+    dy[:, -1] = YY[:, -1] - YY[:, -2]
+    return dy
+
+
+def cal_dx_meters(XX, YY):
+    """SphericalGrid.jl:52-57"""
+    return cal_dx_degree(XX) * np.pi / 180 * (R_EARTH_MESH * np.cos(YY * np.pi / 180))
+
+
+def cal_dy_meters(YY):
+    """SphericalGrid.jl:70-73"""
+    return cal_dy_degree(YY) * np.pi / 180 * R_EARTH_MESH
+
+
+class TwoDSphericalGridStatistics:
+    """SphericalGrid.jl:99-135"""
+
+    def __init__(self, xmin, xmax, Nx: int, ymin, ymax, Ny: int, mask_value=1, angle=0.0, periodic_boundary=(False, False)):
+        self.dimx, self.dimy = xmax - xmin, ymax - ymin
+        self.Ndx, self.Ndy = Nx - 1, Ny - 1
+        self.Nx = N_Periodic(Nx) if periodic_boundary[0] else N_NonPeriodic(Nx)
+        self.Ny = N_Periodic(Ny) if periodic_boundary[1] else N_NonPeriodic(Ny)
+        self.dx_deg, self.dy_deg = self.dimx / self.Ndx, self.dimy / self.Ndy
+        self.xmin, self.xmax, self.ymin, self.ymax = xmin, xmax, ymin, ymax
+        self.angle_dx, self.mask_value = angle, mask_value
+        # the kernels take the projection from the per-node metric; dx, dy are placeholders
+        self.dx = self.dy = 1.0
+
+
+class TwoDSphericalGridMesh:
+    """SphericalGrid.jl:154-203: node lon/lat (degrees), dx/dy/area in metres, total mask.
+    `metric()` gives what the time step needs: the diagonal of ProjetionKernel (:225-237, with the
+    reference's `cos.(Gi.dy * pi / 180)` as written) and the PropagationCorrection coefficient
+    (spherical_grid_corrections.jl:3-21)."""
+
+    def __init__(self, xmin, xmax, Nx: int, ymin, ymax, Ny: int, mask=None, angle=0.0, periodic_boundary=(False, False)):
+        self.stats = TwoDSphericalGridStatistics(xmin, xmax, Nx, ymin, ymax, Ny, angle=angle, periodic_boundary=periodic_boundary)
+        x = xmin + self.stats.dx_deg * np.arange(Nx)
+        y = ymin + self.stats.dy_deg * np.arange(Ny)
+        XX, YY = np.meshgrid(x, y, indexing="ij")
+        dx = cal_dx_meters(XX, YY)
+        dy = cal_dy_meters(YY)
+        if mask is None:
+            mask = np.ones(XX.shape, dtype=bool)
+        total = make_boundaries(np.asarray(mask, dtype=bool), self.stats.Nx, self.stats.Ny)
+        self.data = SimpleNamespace(x=XX, y=YY, dx=dx, dy=dy, area=dx * dy, mask=total)
+
+    def metric(self):
+        d = self.data
+        cos_lat = np.cos(d.dy * np.pi / 180)                      # (sic) SphericalGrid.jl:228
+        with np.errstate(divide="ignore"):
+            m11 = 1.0 / (cos_lat * d.dx)
+            m22 = 1.0 / d.dy
+        phi = d.y
+        sg = np.sign(phi)
+        coef = (sg * np.minimum(sg * np.tan(np.deg2rad(phi)), 60.0)) / R_EARTH_PC
+        return m11, m22, coef

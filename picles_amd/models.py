@@ -15,7 +15,7 @@ import numpy as np
 from . import _capi as K
 from . import fetch_relations as FetchRelations
 from .core_2D import ParticleDefaults
-from .grids import TwoDCartesianGridMesh, N_Periodic, make_boundary_lists
+from .grids import TwoDCartesianGridMesh, TwoDSphericalGridMesh, N_Periodic, make_boundary_lists
 from .particle_waves_v5 import ODESettings, ParticleSystem2D
 
 
@@ -140,6 +140,8 @@ class WaveGrowth2D:
                                    self.periodic_boundary)
         factory = backend_factory or _hip_backend
         self.backend = factory(g, p, o, m, grid.data.mask, **(backend_kwargs or {}))
+        if hasattr(grid, "metric"):     # spherical mesh: per-node projection + great-circle term
+            self.backend.set_metric(*grid.metric())
         self._wind_window = None
 
     # ---- winds ----

@@ -62,6 +62,7 @@ def lib(kind: str = "libm") -> C.CDLL:
         "picles_oracle_is_pmath": (C.c_int32, []),
         "picles_oracle_has_openmp": (C.c_int32, []),
         "picles_oracle_math": (None, [C.c_int32, C.c_int64, DP, DP, DP]),
+        "picles_oracle_set_metric": (C.c_int32, [VP, DP, DP, DP]),
         "picles_oracle_set_halo_rows": (C.c_int32, [VP, C.c_int32]),
         "picles_oracle_halo_rows": (C.c_int32, [VP]),
         "picles_oracle_begin_step": (C.c_int32, [VP, D, C.c_int32]),
@@ -139,6 +140,10 @@ class OracleModel:
             u1 = np.ascontiguousarray(np.asarray(u1, dtype=np.float64).reshape(-1, order="F"))
             v1 = np.ascontiguousarray(np.asarray(v1, dtype=np.float64).reshape(-1, order="F"))
         self.L.picles_oracle_set_winds(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(u1), K.dptr(v1), t1)
+
+    def set_metric(self, m11, m22, pc):
+        a = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, order="F")) for x in (m11, m22, pc)]
+        self.L.picles_oracle_set_metric(self.h, K.dptr(a[0]), K.dptr(a[1]), K.dptr(a[2]))
 
     def seed(self, t0=0.0):
         self.L.picles_oracle_seed(self.h, t0)
