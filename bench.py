@@ -54,12 +54,13 @@ def cpu_baseline(args, W, K):
         dt = time.perf_counter() - t0
         return m.n_stepped * K / dt, dt
 
-    n = 96
+    run(64)                      # spin up the OpenMP team (256-thread pools take ~1 s to start)
+    n = 512
     rate, dt = run(n)
-    for _ in range(4):   # grow the sample until it is ~cpu_seconds of work (bounded at 2048²)
-        if dt >= 0.5 * args.cpu_seconds or n >= 2048:
+    for _ in range(3):           # grow the sample towards ~cpu_seconds of work (bounded at 3072²)
+        if dt >= 0.5 * args.cpu_seconds or n >= 3072:
             break
-        n = int(min(2048, max(n + 8, n * (args.cpu_seconds / max(dt, 1e-3)) ** 0.5)))
+        n = int(min(3072, max(n + 8, n * (args.cpu_seconds / max(dt, 1e-3)) ** 0.5)))
         n -= n % 8
         rate, dt = run(n)
     return {"value": rate, "unit": "particle-steps/s", "cores": threads, "kind": "port",
