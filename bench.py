@@ -26,6 +26,22 @@ FP64_PEAK_TFLOPS = 78.6
 FLOP_PER_RHS = 240.0  # executed fp64 flops per RHS evaluation, all-in (2*FMA + MUL + ADD of the RK loop / 6)
 
 
+def usable_cores():
+    """host cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, W, K):
     """time the CPU oracle (kind 'port': our C restatement, OpenMP over particles) on a bounded
     sample of the same workload: an n×n periodic sub-box with identical physics and winds —
@@ -35,8 +51,8 @@ def cpu_baseline(args, W, K):
     import _oracle as O
     from picles_amd import configs
     from picles_amd.parallel import SlabModel
-    cores = os.cpu_count() or 1
-    threads = min(cores, args.cpu_threads) if args.cpu_threads else cores
+    cores = usable_cores()
+    threads = args.cpu_threads if args.cpu_threads else cores
 
     def fac(g, p, o, m, mask, **kw):
         # pull=True: the node-parallel (OpenMP) scatter; bitwise equal to the sequential push
@@ -65,7 +81,7 @@ def cpu_baseline(args, W, K):
         rate, dt = run(n)
     return {"value": rate, "unit": "particle-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n}x{n} periodic sub-box, same physics/winds, same {W}+{K} steps, {dt:.1f} s of CPU work "
-                      f"(C oracle: OpenMP advance + node-parallel pull scatter, {threads} threads on {cores} host cores)"}
+                      f"(C oracle: OpenMP advance + node-parallel pull scatter, {threads} threads on the {cores} host cores this process may use)"}
 
 
 def measured_traffic(args, world):
