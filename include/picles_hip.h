@@ -195,6 +195,15 @@ int32_t picles_sync(picles_ctx *ctx);
 int32_t picles_begin_step(picles_ctx *ctx, double dt, int32_t flags);
 int32_t picles_advance_rows(picles_ctx *ctx, int32_t which, void *stream);
 int32_t picles_scatter_remesh(picles_ctx *ctx, void *stream);  /* + tick */
+/* Fused form of the same step (DESIGN.md k_step): the scatter + remesh of the PREVIOUS step ride on
+ * the advance launches of the current one, so a model step is picles_step_rows(EDGE) -> exchange ||
+ * picles_step_rows(INTERIOR), with no separate scatter launch.  picles_begin_fused_step returns 1
+ * (and does nothing) when the step cannot be fused — time-varying or gridded winds, a per-node
+ * metric — in which case the plain phases above are used.  The last step's scatter + remesh are
+ * completed lazily by whichever call observes State / particles / counters. */
+int32_t picles_begin_fused_step(picles_ctx *ctx, double dt);
+int32_t picles_step_rows(picles_ctx *ctx, int32_t which, void *stream);
+int32_t picles_end_fused_step(picles_ctx *ctx);
 /* device pointers + byte count of the contiguous halo blocks (halo_rows record rows each):
  * side 0 = low-j neighbour, 1 = high-j neighbour */
 int32_t picles_halo_send_dev(picles_ctx *ctx, int32_t side, void **ptr, size_t *bytes);

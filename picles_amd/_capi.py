@@ -130,6 +130,9 @@ SYMBOLS = {
     "picles_begin_step": (C.c_int32, [_VP, C.c_double, C.c_int32]),
     "picles_advance_rows": (C.c_int32, [_VP, C.c_int32, _VP]),
     "picles_scatter_remesh": (C.c_int32, [_VP, _VP]),
+    "picles_begin_fused_step": (C.c_int32, [_VP, C.c_double]),
+    "picles_step_rows": (C.c_int32, [_VP, C.c_int32, _VP]),
+    "picles_end_fused_step": (C.c_int32, [_VP]),
     "picles_halo_send_dev": (C.c_int32, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_size_t)]),
     "picles_halo_recv_dev": (C.c_int32, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_size_t)]),
     "picles_halo_rows": (C.c_int32, [_VP]),

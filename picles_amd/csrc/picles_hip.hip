@@ -472,13 +472,14 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * ---------------------------------------------------------------------------------------- */
 template <bool FAST>
 __global__ void __launch_bounds__(256) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
-                                                double t_start, double DT)
+                                                double t_start, double DT, int r0, int n0, int r1, int n1)
 {
     dp_device_init();
     pm_device_init();
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long t = 0;
+    bool active = rows_index(G, r0, n0, r1, n1, t);
     StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0};
-    if (t < A.n) {
+    if (active) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         int R = G.Rp;
@@ -819,6 +820,7 @@ static int flush(picles_ctx *c)
 {
     if (!c->pending) return 0;
     c->pending = false;
+    HIPCHK(c, hipDeviceSynchronize());   /* the fused launches may have run on caller-provided streams */
     double clock_save = c->clock, dt_save = c->step_dt;
     int flags_save = c->step_flags;
     c->clock = c->pend_t;           /* remesh samples the wind at the start-of-step clock */
@@ -1161,29 +1163,43 @@ PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
     return 0;
 }
 
+static int select_rows(picles_ctx *c, int which, int &r0, int &n0, int &r1, int &n1)
+{
+    const GridP &G = c->G;
+    int R = G.R;
+    r0 = n0 = r1 = n1 = 0;
+    bool small = G.ny_loc <= 2 * R;
+    if (which == PICLES_ROWS_ALL) { n0 = G.ny_loc; }
+    else if (which == PICLES_ROWS_EDGE) {
+        if (small) n0 = G.ny_loc;
+        else { n0 = R; r1 = G.ny_loc - R; n1 = R; }
+    } else if (which == PICLES_ROWS_INTERIOR) {
+        if (!small) { r0 = R; n0 = G.ny_loc - 2 * R; }
+    } else return fail(c, -2, "bad row selector");
+    return 0;
+}
+
+/* first launch of a step on stream s: clear the per-step reach counter there */
+static int step_prologue(picles_ctx *c, hipStream_t s)
+{
+    if (c->step_fresh) {
+        HIPCHK(c, hipMemsetAsync(c->mr_buf[c->cur], 0, sizeof(int), s));
+        c->step_fresh = false;
+    }
+    return 0;
+}
+
 PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    const GridP &G = c->G;
-    int R = G.R;
-    int r0 = 0, n0 = 0, r1 = 0, n1 = 0;
-    bool small = G.ny_loc <= 2 * R;
-    if (which == PICLES_ROWS_ALL) { r0 = 0; n0 = G.ny_loc; }
-    else if (which == PICLES_ROWS_EDGE) {
-        if (small) { r0 = 0; n0 = G.ny_loc; }
-        else { r0 = 0; n0 = R; r1 = G.ny_loc - R; n1 = R; }
-    } else if (which == PICLES_ROWS_INTERIOR) {
-        if (small) return 0;
-        r0 = R; n0 = G.ny_loc - 2 * R;
-    } else return fail(c, -2, "bad row selector");
-    long long nt = (long long)(n0 + n1) * G.Nx;
+    int r0, n0, r1, n1;
+    int rc = select_rows(c, which, r0, n0, r1, n1);
+    if (rc) return rc;
+    long long nt = (long long)(n0 + n1) * c->G.Nx;
     if (nt == 0) return 0;
-    if (c->step_fresh) {   /* max_reach is a per-step quantity */
-        HIPCHK(c, hipMemsetAsync(c->mr_buf[c->cur], 0, sizeof(int), s));
-        c->step_fresh = false;
-    }
+    if ((rc = step_prologue(c, s))) return rc;
     timing_begin(c, s, 0);
     {
         const KParams &P = c->P;
@@ -1204,6 +1220,73 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
         HIPCHK(c, hipEventRecord(c->ev_edge, s));
         c->edge_pending = true;
     }
+    return 0;
+}
+
+/* can this step ride on fused k_step launches? (run!-style: State zeroed first, static winds) */
+static bool step_fusable(const picles_ctx *c, int flags)
+{
+    return (flags == PICLES_STEP_ZERO_FIRST) && c->P.wind_static && !c->wind_grid_on && c->fuse_steps && !c->A.pc;
+}
+
+/* fused phase launcher: scatter+remesh of the pending step and advance of the current one for the
+ * selected rows (records of the pending step: rec_buf[1-cur], of this step: rec_buf[cur]) */
+static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
+{
+    int r0, n0, r1, n1;
+    int rc = select_rows(c, which, r0, n0, r1, n1);
+    if (rc) return rc;
+    long long nt = (long long)(n0 + n1) * c->G.Nx;
+    if (nt == 0) return 0;
+    if ((rc = step_prologue(c, s))) return rc;
+    const KParams &P = c->P;
+    Arrays A = arrays_for(c, c->cur ^ 1, c->cur);
+    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+    dim3 grid(nblocks(nt, 256)), block(256);
+    timing_begin(c, s, 0);
+    if (fast) hipLaunchKernelGGL((k_step<true>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1);
+    else hipLaunchKernelGGL((k_step<false>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1);
+    timing_end(c, s);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+/* Slab form of the fused step.  Per model step:
+ *   picles_begin_fused_step(dt)            (returns 1 if the step cannot be fused: use the plain phases)
+ *   picles_step_rows(EDGE, stream_E)  ->  exchange halo blocks  ||  picles_step_rows(INTERIOR, stream_M)
+ *   picles_end_fused_step()                (ticks the clock; scatter+remesh of this step stay pending) */
+PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
+{
+    if (!c) return -1;
+    if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
+    if (!step_fusable(c, PICLES_STEP_ZERO_FIRST)) return 1;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->step_dt = dt;
+    c->step_flags = PICLES_STEP_ZERO_FIRST;
+    c->edge_pending = false;
+    c->cur ^= 1;
+    c->step_fresh = true;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_step_rows(picles_ctx *c, int32_t which, void *stream)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!c->pending) return picles_advance_rows(c, which, stream);   /* first step: nothing to scatter yet */
+    return launch_step_rows(c, which, s);
+}
+
+PX_EXPORT int32_t picles_end_fused_step(picles_ctx *c)
+{
+    if (!c) return -1;
+    c->pending = true;
+    c->pend_t = c->clock;
+    c->pend_dt = c->step_dt;
+    c->state_zero = false;
+    c->edge_pending = false;
+    c->clock += c->step_dt;
     return 0;
 }
 
@@ -1263,38 +1346,13 @@ PX_EXPORT int32_t picles_time_step(picles_ctx *c, double dt, int32_t flags)
     if (!c) return -1;
     if (!c->G.single_slab) return fail(c, -5, "picles_time_step needs the whole grid; slabs use begin_step/advance_rows/scatter_remesh");
     if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
-    const KParams &P = c->P;
-    bool fusable = (flags == PICLES_STEP_ZERO_FIRST) && P.wind_static && !c->wind_grid_on && c->fuse_steps && !c->A.pc;
-    if (fusable) {
+    if (step_fusable(c, flags)) {
         /* run!-style consecutive steps: one launch per step (k_step), the scatter + remesh of the
          * previous step ride along; the last one is flushed when somebody looks */
-        HIPCHK(c, hipSetDevice(c->device));
-        if (!c->pending) {
-            int rc0 = picles_begin_step(c, dt, flags);
-            if (rc0) return rc0;
-            rc0 = picles_advance_rows(c, PICLES_ROWS_ALL, nullptr);
-            if (rc0) return rc0;
-        } else {
-            int prev = c->cur;
-            c->cur ^= 1;
-            HIPCHK(c, hipMemsetAsync(c->mr_buf[c->cur], 0, sizeof(int), c->stream));
-            Arrays A = arrays_for(c, prev, c->cur);
-            bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
-            dim3 grid(nblocks(c->A.n, 256)), block(256);
-            timing_begin(c, c->stream, 0);
-            if (fast) hipLaunchKernelGGL((k_step<true>), grid, block, 0, c->stream, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, dt);
-            else hipLaunchKernelGGL((k_step<false>), grid, block, 0, c->stream, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, dt);
-            timing_end(c, c->stream);
-            HIPCHK(c, hipGetLastError());
-            c->step_dt = dt;
-            c->step_flags = flags;
-        }
-        c->pending = true;
-        c->pend_t = c->clock;
-        c->pend_dt = dt;
-        c->state_zero = false;
-        c->clock += dt;
-        return 0;
+        int rc0 = picles_begin_fused_step(c, dt);
+        if (rc0) return rc0 < 0 ? rc0 : fail(c, -6, "internal: fusable step refused");
+        if ((rc0 = picles_step_rows(c, PICLES_ROWS_ALL, nullptr))) return rc0;
+        return picles_end_fused_step(c);
     }
     int rc = picles_begin_step(c, dt, flags);
     if (rc) return rc;

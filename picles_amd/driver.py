@@ -124,6 +124,19 @@ class HipModel:
     def scatter_remesh(self, stream=None):
         self._ck(self.lib.picles_scatter_remesh(self.h, stream), "picles_scatter_remesh")
 
+    def begin_fused_step(self, dt) -> bool:
+        """True if the step runs as fused k_step launches (step_rows / end_fused_step)"""
+        rc = self.lib.picles_begin_fused_step(self.h, dt)
+        if rc < 0:
+            self._ck(rc, "picles_begin_fused_step")
+        return rc == 0
+
+    def step_rows(self, which, stream=None):
+        self._ck(self.lib.picles_step_rows(self.h, which, stream), "picles_step_rows")
+
+    def end_fused_step(self):
+        self._ck(self.lib.picles_end_fused_step(self.h), "picles_end_fused_step")
+
     def halo_send(self, side):
         p, n = C.c_void_p(), C.c_size_t()
         self._ck(self.lib.picles_halo_send_dev(self.h, side, C.byref(p), C.byref(n)), "picles_halo_send_dev")

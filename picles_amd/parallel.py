@@ -201,17 +201,21 @@ class SlabModel:
             b.time_step(dt, flags)
         elif self.use_streams:
             torch = self.ex.torch
-            b.begin_step(dt, flags)
-            # the previous step's scatter+remesh (stream M) wrote the particles and read the records
-            # that the edge advance is about to read / overwrite
+            fused = (flags == K.STEP_ZERO_FIRST) and hasattr(b, "begin_fused_step") and b.begin_fused_step(dt)
+            if not fused:
+                b.begin_step(dt, flags)
+            # the previous step's work on stream M wrote / read what the edge launch is about to touch
             self.s_edge.wait_stream(self.s_main)
             with torch.cuda.stream(self.s_edge):
-                b.advance_rows(K.ROWS_EDGE, self.s_edge.cuda_stream)
+                (b.step_rows if fused else b.advance_rows)(K.ROWS_EDGE, self.s_edge.cuda_stream)
                 works = self.ex.start()            # RCCL send/recv ordered after the edge kernel
-            b.advance_rows(K.ROWS_INTERIOR, self.s_main.cuda_stream)
+            (b.step_rows if fused else b.advance_rows)(K.ROWS_INTERIOR, self.s_main.cuda_stream)
             with torch.cuda.stream(self.s_main):
                 self.ex.finish(works)              # s_main waits for the halo
-                b.scatter_remesh(self.s_main.cuda_stream)
+                if fused:
+                    b.end_fused_step()             # scatter + remesh ride on the next step's launches
+                else:
+                    b.scatter_remesh(self.s_main.cuda_stream)
         else:
             b.begin_step(dt, flags)
             b.advance_rows(K.ROWS_EDGE)
