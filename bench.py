@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")
     args = ap.parse_args()
 
     import torch
@@ -123,11 +125,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    if args.backend == "gloo":
+        local_rank = 0            # rehearsal: every rank on the one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from picles_amd import configs, _capi as K
     from picles_amd.parallel import SlabModel
@@ -160,7 +167,8 @@ def main():
     tim = model.backend.get_timing()
     n_local = model.n_stepped
     vals = torch.tensor([elapsed, float(n_local), float(cnt["rhs_evals"]), float(cnt["halo_overflow"]),
-                         float(cnt["steps_accepted"]), float(cnt["steps_rejected"])], dtype=torch.float64, device="cuda")
+                         float(cnt["steps_accepted"]), float(cnt["steps_rejected"])], dtype=torch.float64,
+                        device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
