@@ -60,6 +60,7 @@ def cpu_baseline(args, W, K):
 
     def run(n):
         cfg = configs.box4096(n=n, U10=args.winds[0], V10=args.winds[1])
+        cfg.model["ODEsys"].dir_deadband = getattr(args, "deadband", 0.0)
         m = SlabModel(cfg.model, 0, 1, backend_factory=fac)
         m.seed()
         for _ in range(W):
@@ -111,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--deadband", type=float, default=0.0,
+                    help="opt-in picles_phys.dir_deadband (0 = reference-exact RHS; the headline number uses 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")
     args = ap.parse_args()
@@ -140,6 +143,7 @@ def main():
     from picles_amd.parallel import SlabModel
 
     cfg = configs.box4096(n=args.n, U10=args.winds[0], V10=args.winds[1])
+    cfg.model["ODEsys"].dir_deadband = args.deadband
     model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo)
     model.seed()
     flags = K.STEP_ZERO_FIRST | (K.STEP_ATOMIC if args.atomic else 0)
@@ -210,6 +214,7 @@ def main():
                 "particles": int(n_total),
                 "parallelism": f"y-slabs x{world}, forward halo of scatter records ({args.halo} row) over RCCL send/recv",
                 "scatter": "atomic-push" if args.atomic else "deterministic-pull",
+                "dir_deadband": args.deadband,
             },
             "hbm_GBps_path": B_ALG * value / 1e9,
             "roofline": {

@@ -51,6 +51,11 @@ typedef struct picles_phys {
     double gamma, q;                      /* particle_equations(u,v; γ, q)                  */
     double c_beta, c_D, c_e, c_alpha;     /* IDConstants fields entering e_T_func :271      */
     int32_t propagation, input, dissipation, peak_shift, direction;  /* RHS switches :383-387 */
+    int32_t _pad0;
+    double  dir_deadband;   /* OPT-IN, 0 = off (reference-exact).  |sin(θ_c - θ_w)| below this value is
+                               treated as exact alignment in S_dir (particle_waves_v5.jl:345-346): round-off
+                               misalignment (~1e-16) otherwise excites the stiff direction mode of the
+                               explicit stepper.  1e-9 changes the RHS by < 1e-9 relative. */
 } picles_phys;
 
 /* ---- ODESettings (particle_waves_v5.jl:34-75) ---------------------------------- */

@@ -257,6 +257,10 @@ static void po_rhs_literal(const po_model *M, int64_t idx, const double z[5], do
         else
             s2 = (2.0 / (UG * UG)) *
                  (u * v * (2.0 * (gy * gy) - sg * sg) - gx * gy * (2.0 * (v * v) - U * U));
+        if (ph->dir_deadband > 0.0) {   /* opt-in dead band on |sin(θ_c - θ_w)| = |u gy - v gx| / (U |g|) */
+            double crs = u * gy - v * gx;
+            if (crs * crs <= ph->dir_deadband * ph->dir_deadband * (UG * UG)) s2 = 0.0;
+        }
         Sd = a2 * a2 * ph->C_phi * H * s2;
     }
     dz[0] = wp * r_g * Scg + wp * (It - Dt);               /* :526 */
@@ -336,6 +340,10 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
             s2 = 0.0;
         else
             s2 = ((2.0 * crs) * dot) * (rc2 * (1.0 / U2));
+        {   /* opt-in dead band (picles_phys.dir_deadband) */
+            double db2 = ph->dir_deadband * ph->dir_deadband;
+            if (db2 > 0.0 && crs * crs <= db2 * (U2 * (cgp * cgp))) s2 = 0.0;
+        }
         Sd = (((alpha * alpha) * ph->C_phi) * H) * s2;
     }
     double wrS = (wp * ph->r_g) * Scg;

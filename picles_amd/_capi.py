@@ -37,7 +37,8 @@ class PiclesPhys(C.Structure):
         ("gamma", C.c_double), ("q", C.c_double),
         ("c_beta", C.c_double), ("c_D", C.c_double), ("c_e", C.c_double), ("c_alpha", C.c_double),
         ("propagation", C.c_int32), ("input", C.c_int32), ("dissipation", C.c_int32),
-        ("peak_shift", C.c_int32), ("direction", C.c_int32),
+        ("peak_shift", C.c_int32), ("direction", C.c_int32), ("_pad0", C.c_int32),
+        ("dir_deadband", C.c_double),
     ]
 
 

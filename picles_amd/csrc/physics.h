@@ -30,6 +30,7 @@ struct KParams {
     double r_g, inv_rg, C_alpha, C_phi, C_e;
     double p, n, neg2p, inv_eT;
     double inv_dx, inv_dy;
+    double deadband2;       /* dir_deadband² (0 = off) */
     int propagation, input, dissipation, peak_shift, direction, n_is_2;
     /* ODE settings */
     double abstol, reltol, dt0, dtmin;
@@ -299,6 +300,8 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
             s2 = 0.0;
         else
             s2 = ((2.0 * crs) * dot) * (rc2 * W.invU2);
+        /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned */
+        if (P.deadband2 > 0.0 && crs * crs <= P.deadband2 * (W.U2 * (cgp * cgp))) s2 = 0.0;
         Sd = (((alpha * alpha) * P.C_phi) * H) * s2;
     }
     double wrS = (wp * P.r_g) * Scg;

@@ -838,6 +838,8 @@ PX_EXPORT const char *picles_last_error(const picles_ctx *ctx)
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
+PX_EXPORT int32_t picles_destroy(picles_ctx *c);
+
 PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, const picles_ode *o,
                                 const picles_model *m, int32_t device_id, int32_t halo_rows, picles_ctx **out)
 {
@@ -857,6 +859,9 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = hipGetErrorString(e); return -4; }
 
     picles_ctx *c = new picles_ctx();
+    memset(&c->A, 0, sizeof(c->A));
+    c->stream = nullptr;
+    c->ev_edge = nullptr;
     c->g = *g; c->ph = *p; c->od = *o; c->md = *m;
     c->device = device_id;
     /* derived constants: magic_fractions :87-92, e_T_func :271 (same primitives as the kernels) */
@@ -869,6 +874,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     double e_T = std::sqrt(p->c_e * pm_pow(p->c_alpha, -P.p / q) / pm_pow(p->gamma * p->c_beta * p->c_D, 1.0 / P.n));
     P.inv_eT = 1.0 / e_T;
     P.inv_dx = 1.0 / g->dx; P.inv_dy = 1.0 / g->dy;
+    P.deadband2 = p->dir_deadband * p->dir_deadband;
     P.propagation = p->propagation; P.input = p->input; P.dissipation = p->dissipation;
     P.peak_shift = p->peak_shift; P.direction = p->direction; P.n_is_2 = (P.n == 2.0);
     P.abstol = o->abstol; P.reltol = o->reltol; P.dt0 = o->dt0; P.dtmin = o->dtmin;
@@ -924,7 +930,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
         }
     }
 
-#define CK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e2); delete c; return -10; } } while (0)
+#define CK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e2); picles_destroy(c); return -10; } } while (0)
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
     Arrays &A = c->A;
@@ -959,7 +965,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
 {
     if (!c) return 0;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     Arrays &A = c->A;
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
@@ -979,8 +985,8 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     if (c->d_scan_tmp) hipFree(c->d_scan_tmp);
     for (auto &e : c->ev_used) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto &e : c->ev_free) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    hipEventDestroy(c->ev_edge);
-    hipStreamDestroy(c->stream);
+    if (c->ev_edge) hipEventDestroy(c->ev_edge);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -1606,6 +1612,10 @@ PX_EXPORT int32_t picles_scatter_particles(picles_ctx *c, int64_t np, const int3
     int ntiles = ntx * nty;
     int *d_ij = nullptr, *d_tile = nullptr, *d_perm = nullptr;
     double *d_xy = nullptr, *d_ch = nullptr;
+    struct Tmp {   /* released on every exit path */
+        int *&a, *&b, *&c2; double *&d, *&e;
+        ~Tmp() { hipFree(a); hipFree(b); hipFree(c2); hipFree(d); hipFree(e); }
+    } tmp{d_ij, d_tile, d_perm, d_xy, d_ch};
     HIPCHK(c, hipMalloc(&d_ij, 2 * np * 4)); HIPCHK(c, hipMalloc(&d_tile, np * 4)); HIPCHK(c, hipMalloc(&d_perm, np * 4));
     HIPCHK(c, hipMalloc(&d_xy, 2 * np * 8)); HIPCHK(c, hipMalloc(&d_ch, 3 * np * 8));
     if (!c->d_count) {
@@ -1628,7 +1638,6 @@ PX_EXPORT int32_t picles_scatter_particles(picles_ctx *c, int64_t np, const int3
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
-    hipFree(d_ij); hipFree(d_tile); hipFree(d_perm); hipFree(d_xy); hipFree(d_ch);
     c->state_zero = false;
     return 0;
 }

@@ -33,6 +33,8 @@ struct picles_phys
     gamma::Float64; q::Float64
     c_beta::Float64; c_D::Float64; c_e::Float64; c_alpha::Float64
     propagation::Int32; input::Int32; dissipation::Int32; peak_shift::Int32; direction::Int32
+    _pad0::Int32
+    dir_deadband::Float64
 end
 
 struct picles_ode
@@ -93,7 +95,7 @@ function WaveGrowth2DHIP(; grid::TwoDCartesianGridMesh, winds, ODEsets, γ, q, I
                         pointer(mask), 0, st.Ny.N))
     p = Ref(picles_phys(P.r_g, P.C_α, P.C_φ, P.C_e, P.g, γ, q,
                         IDConstants.c_β, IDConstants.c_D, IDConstants.c_e, IDConstants.c_alpha,
-                        propagation, input, dissipation, peak_shift, direction))
+                        propagation, input, dissipation, peak_shift, direction, 0, 0.0))
     o = Ref(picles_ode(ODEsets.abstol, ODEsets.reltol, ODEsets.dt, ODEsets.dtmin, ODEsets.force_dtmin, 0,
                        ODEsets.maxiters, ODEsets.log_energy_minimum, ODEsets.log_energy_maximum,
                        ODEsets.wind_min_squared, ODEsets.timestep))

@@ -48,6 +48,7 @@ def build_structs(grid: TwoDCartesianGridMesh, ODEsys: ParticleSystem2D, ODEsets
     p.c_beta, p.c_D, p.c_e, p.c_alpha = idc.c_β, idc.c_D, idc.c_e, idc.c_alpha
     p.propagation, p.input, p.dissipation = int(ODEsys.propagation), int(ODEsys.input), int(ODEsys.dissipation)
     p.peak_shift, p.direction = int(ODEsys.peak_shift), int(ODEsys.direction)
+    p.dir_deadband = float(getattr(ODEsys, "dir_deadband", 0.0))
     o = K.PiclesOde()
     if ODEsets.solver not in ("DP5",):
         raise NotImplementedError(f"solver {ODEsets.solver!r}: the kernel implements DP5 (DESIGN.md)")

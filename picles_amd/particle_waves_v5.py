@@ -92,6 +92,7 @@ class ParticleSystem2D:
     dissipation: bool = True
     peak_shift: bool = True
     direction: bool = True
+    dir_deadband: float = 0.0   # opt-in (not in the reference): see include/picles_hip.h picles_phys.dir_deadband
 
     @property
     def e_T(self) -> float:

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     # field-by-field mirrors of the C structs (x86-64 SysV): sizes as the compiler lays them out
     assert C.sizeof(K.PiclesGrid) == 48
-    assert C.sizeof(K.PiclesPhys) == 11 * 8 + 5 * 4 + 4
+    assert C.sizeof(K.PiclesPhys) == 11 * 8 + 6 * 4 + 8
     assert C.sizeof(K.PiclesOde) == 4 * 8 + 2 * 4 + 8 + 4 * 8
     assert C.sizeof(K.PiclesModel) == 8 + 5 * 8
     assert C.sizeof(K.PiclesCounters) == 8 * 8 + 8

@@ -1,0 +1,35 @@
+"""Opt-in direction dead band (picles_phys.dir_deadband, default 0 = reference-exact): with a generic wind
+direction round-off excites the stiff direction mode and the explicit stepper is stability-limited;
+treating |sin(θ_c-θ_w)| < 1e-9 as aligned removes that, changing the solution far below the ODE tolerance."""
+import numpy as np
+import pytest
+
+from picles_amd import configs
+from helpers import run_states, assert_bitwise
+
+
+def _cfg(db):
+    cfg = configs.T04_2D_reg_test(U10=10.0, V10=3.0, n=15, L=56e3)
+    cfg.model["ODEsys"].dir_deadband = db
+    return cfg
+
+
+def test_deadband_cuts_work_not_accuracy():
+    m0, S0 = run_states(_cfg(0.0), ("pmath", 1), 8)
+    m1, S1 = run_states(_cfg(1e-9), ("pmath", 1), 8)
+    c0, c1 = m0.backend.get_counters(), m1.backend.get_counters()
+    assert c1["rhs_evals"] * 5 < c0["rhs_evals"]                       # > 5x fewer RHS evaluations
+    a, b = S0[-1][..., 0], S1[-1][..., 0]
+    assert np.nanmax(np.abs(a - b)) < 2e-2 * np.abs(a).max()           # both inside the stepper's C_phi=0.04 tolerance
+    # and the dead-band run is the one closer to the converged anchor family: it equals the exactly aligned case
+    mA, SA = run_states(configs.T04_2D_reg_test(U10=10.0, V10=3.0, n=15, L=56e3), ("libm", 0), 8)
+    assert np.nanmax(np.abs(SA[-1][..., 0] - b)) < 2e-2 * np.abs(a).max()
+
+
+@pytest.mark.gpu
+def test_deadband_gpu_bitwise():
+    mg, G = run_states(_cfg(1e-9), "hip", 6)
+    mo, O = run_states(_cfg(1e-9), ("pmath", 1), 6)
+    for k, (a, b) in enumerate(zip(G, O)):
+        assert_bitwise(a, b, f"State step {k}")
+    assert mg.backend.get_counters()["rhs_evals"] == mo.backend.get_counters()["rhs_evals"]
