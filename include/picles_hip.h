@@ -64,7 +64,8 @@ typedef struct picles_ode {
     double  dt0;             /* ODESettings.dt : initial dt of a freshly built integrator   */
     double  dtmin;
     int32_t force_dtmin;
-    int32_t solver;          /* 0 = DP5 (Dormand-Prince 5(4), bench06:93)                   */
+    int32_t solver;          /* 0 = DP5 (Dormand-Prince 5(4), bench06:93); 1 = Tsit5 (the explicit
+                                half of the ODESettings default AutoTsit5(Rosenbrock23()))    */
     int64_t maxiters;        /* per model step                        */
     double  log_energy_minimum, log_energy_maximum, wind_min_squared;
     double  timestep;        /* ODESettings.timestep: seed time-scale of init_particles!    */

@@ -62,19 +62,27 @@ static inline double o_exp10(double x) { return pow(10.0, x); }
  * ---------------------------------------------------------------------------------------- */
 #define G0 9.81 /* hard default of c_g_conversions_vector, particle_waves_v5.jl:281-287 */
 
-/* Dormand-Prince 5(4) tableau (OrdinaryDiffEq DP5 == scipy.integrate RK45 A,B,C,E) */
-static const double A21 = 1.0 / 5.0;
-static const double A31 = 3.0 / 40.0, A32 = 9.0 / 40.0;
-static const double A41 = 44.0 / 45.0, A42 = -56.0 / 15.0, A43 = 32.0 / 9.0;
-static const double A51 = 19372.0 / 6561.0, A52 = -25360.0 / 2187.0, A53 = 64448.0 / 6561.0,
-                    A54 = -212.0 / 729.0;
-static const double A61 = 9017.0 / 3168.0, A62 = -355.0 / 33.0, A63 = 46732.0 / 5247.0,
-                    A64 = 49.0 / 176.0, A65 = -5103.0 / 18656.0;
-static const double A71 = 35.0 / 384.0, A73 = 500.0 / 1113.0, A74 = 125.0 / 192.0,
-                    A75 = -2187.0 / 6784.0, A76 = 11.0 / 84.0;
-static const double C2 = 1.0 / 5.0, C3 = 3.0 / 10.0, C4 = 4.0 / 5.0, C5 = 8.0 / 9.0;
-static const double E1 = -71.0 / 57600.0, E3 = 71.0 / 16695.0, E4 = -71.0 / 1920.0,
-                    E5 = 17253.0 / 339200.0, E6 = -22.0 / 525.0, E7 = 1.0 / 40.0;
+/* Dormand-Prince 5(4) tableau (OrdinaryDiffEq DP5 == scipy.integrate RK45 A,B,C,E): PO_DP5 in po_dp5_try */
+
+/* Tsitouras 5(4) tableau (OrdinaryDiffEq Tsit5 constant cache; Ch. Tsitouras, Comput. Math. Appl. 62
+ * (2011) 770-775).  Checked against the order conditions in tests/test_tableaux.py. */
+typedef struct po_tab {
+    double a21, a31, a32, a41, a42, a43, a51, a52, a53, a54, a61, a62, a63, a64, a65;
+    double a71, a72, a73, a74, a75, a76, c2, c3, c4, c5, e1, e2, e3, e4, e5, e6, e7;
+    double beta1, beta2;
+    int has2;
+} po_tab;
+
+static const po_tab PO_TSIT5 = {
+    0.161, -0.008480655492356989, 0.335480655492357,
+    2.8971530571054935, -6.359448489975075, 4.3622954328695815,
+    5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525,
+    5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383,
+    0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774,
+    0.161, 0.327, 0.9, 0.9800255409045097,
+    -0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+    0.5823571654525552, -0.45808210592918697, 0.015151515151515152,
+    0.14, 0.08, 1};
 
 /* OrdinaryDiffEq PI controller defaults for DP5 (alg_utils.jl: beta2 = 4//100,
  * beta1 = 1//5 - 3beta2/4, gamma = 9//10, qmin = 1//5, qmax = 10, qoldinit = 1//10^4) */
@@ -456,6 +464,47 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
                          double t, double h, double unew[5], double k7[5], po_pstats *st)
 {
     const picles_ode *od = &M->od;
+    /* tableau of the selected solver (od->solver: 0 DP5, 1 Tsit5); same 7-stage FSAL structure */
+    static const po_tab PO_DP5 = {1.0 / 5.0, 3.0 / 40.0, 9.0 / 40.0, 44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0,
+                                  19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0,
+                                  9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0,
+                                  35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0,
+                                  1.0 / 5.0, 3.0 / 10.0, 4.0 / 5.0, 8.0 / 9.0,
+                                  -71.0 / 57600.0, 0.0, 71.0 / 16695.0, -71.0 / 1920.0, 17253.0 / 339200.0, -22.0 / 525.0, 1.0 / 40.0,
+                                  0.17, 0.04, 0};
+    const po_tab *T = od->solver ? &PO_TSIT5 : &PO_DP5;
+#define A21 T->a21
+#define A31 T->a31
+#define A32 T->a32
+#define A41 T->a41
+#define A42 T->a42
+#define A43 T->a43
+#define A51 T->a51
+#define A52 T->a52
+#define A53 T->a53
+#define A54 T->a54
+#define A61 T->a61
+#define A62 T->a62
+#define A63 T->a63
+#define A64 T->a64
+#define A65 T->a65
+#define A71 T->a71
+#define A72 T->a72
+#define A73 T->a73
+#define A74 T->a74
+#define A75 T->a75
+#define A76 T->a76
+#define C2 T->c2
+#define C3 T->c3
+#define C4 T->c4
+#define C5 T->c5
+#define E1 T->e1
+#define E2 T->e2
+#define E3 T->e3
+#define E4 T->e4
+#define E5 T->e5
+#define E6 T->e6
+#define E7 T->e7
     double k2[5], k3[5], k4[5], k5[5], k6[5], g[5], uw, vw;
     int K = M->order;
 #define STAGE(expr_lit, expr_k) for (int i = 0; i < 5; i++) g[i] = K ? (expr_k) : (expr_lit)
@@ -485,8 +534,14 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
     po_wind(M, idx, t + h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k6);
     for (int i = 0; i < 5; i++)
-        unew[i] = K ? PO_FMA(h, PO_FMA(A76, k6[i], PO_FMA(A75, k5[i], PO_FMA(A74, k4[i], PO_FMA(A73, k3[i], A71 * k1[i])))), u0[i])
-                    : u0[i] + h * (A71 * k1[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+        if (K) {
+            double s72 = T->has2 ? PO_FMA(A72, k2[i], A71 * k1[i]) : A71 * k1[i];
+            unew[i] = PO_FMA(h, PO_FMA(A76, k6[i], PO_FMA(A75, k5[i], PO_FMA(A74, k4[i], PO_FMA(A73, k3[i], s72)))), u0[i]);
+        } else if (T->has2) {   /* Tsit5 perform_step!: a71 k1 + a72 k2 + ... */
+            unew[i] = u0[i] + h * (A71 * k1[i] + A72 * k2[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+        } else {                /* DP5 perform_step!: the zero a72 term does not appear */
+            unew[i] = u0[i] + h * (A71 * k1[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
+        }
     po_rhs(M, idx, unew, uw, vw, k7);
     st->rhs += 6;
 #undef STAGE
@@ -495,14 +550,48 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
         double ut, m0 = fabs(u0[i]), m1 = fabs(unew[i]);
         double mm = (m0 > m1) ? m0 : m1;
         if (!K) {
-            ut = h * (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k7[i]);
+            if (T->has2) ut = h * (E1 * k1[i] + E2 * k2[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k7[i]);
+            else ut = h * (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k7[i]);
             at[i] = ut / (od->abstol + mm * od->reltol);
         } else {
-            ut = h * PO_FMA(E7, k7[i], PO_FMA(E6, k6[i], PO_FMA(E5, k5[i], PO_FMA(E4, k4[i], PO_FMA(E3, k3[i], E1 * k1[i])))));
+            double e12 = T->has2 ? PO_FMA(E2, k2[i], E1 * k1[i]) : E1 * k1[i];
+            ut = h * PO_FMA(E7, k7[i], PO_FMA(E6, k6[i], PO_FMA(E5, k5[i], PO_FMA(E4, k4[i], PO_FMA(E3, k3[i], e12)))));
             at[i] = ut / PO_FMA(mm, od->reltol, od->abstol);
         }
     }
     return K ? po_norm5_k(at) : po_norm5_lit(at);
+#undef A21
+#undef A31
+#undef A32
+#undef A41
+#undef A42
+#undef A43
+#undef A51
+#undef A52
+#undef A53
+#undef A54
+#undef A61
+#undef A62
+#undef A63
+#undef A64
+#undef A65
+#undef A71
+#undef A72
+#undef A73
+#undef A74
+#undef A75
+#undef A76
+#undef C2
+#undef C3
+#undef C4
+#undef C5
+#undef E1
+#undef E2
+#undef E3
+#undef E4
+#undef E5
+#undef E6
+#undef E7
 }
 
 /* step!(integrator, DT, true): integrate particle idx from clock to clock+DT. */
@@ -517,6 +606,8 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
     st->rhs++;
     double dt = *dtn;
     if (!(dt > 0.0)) dt = po_initdt(M, idx, z, k1, t_start, st);
+    /* beta2_default / beta1_default (OrdinaryDiffEq alg_utils.jl): DP5 4//100, 1//5 - 3beta2/4; Tsit5 2//25, 7//50 */
+    const double beta1 = od->solver ? 0.14 : CTRL_BETA1, beta2 = od->solver ? 0.08 : CTRL_BETA2;
     int64_t iter = 0;
     while (tr < DT) {
         iter++;
@@ -534,7 +625,7 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
             double le = o_log(EEst);
             if (accept) {
                 st->acc++;
-                double qi = o_exp(PO_FMA(CTRL_BETA2, *qold, -(CTRL_BETA1 * le))) * CTRL_GAMMA;
+                double qi = o_exp(PO_FMA(beta2, *qold, -(beta1 * le))) * CTRL_GAMMA;
                 qi = (qi > CTRL_QMAX) ? CTRL_QMAX : qi;
                 qi = (qi < CTRL_QMIN) ? CTRL_QMIN : qi;
                 *qold = (le > CTRL_LNQOLDINIT) ? le : CTRL_LNQOLDINIT;
@@ -544,7 +635,7 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
                 if (z[0] != z[0] || z[1] != z[1] || z[2] != z[2] || z[3] != z[3] || z[4] != z[4]) break;
             } else {
                 st->rej++;
-                double r = CTRL_GAMMA * o_exp(-(CTRL_BETA1 * le));
+                double r = CTRL_GAMMA * o_exp(-(beta1 * le));
                 r = (r < CTRL_QMIN) ? CTRL_QMIN : r;
                 dt = h * r;
                 if (!od->force_dtmin && h <= od->dtmin) { st->status |= PICLES_ST_DTMIN; break; }
@@ -556,8 +647,8 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
         if (EEst == 0.0) {
             q = 1.0 / CTRL_QMAX;
         } else {
-            q11 = o_pow(EEst, CTRL_BETA1);
-            q = q11 / o_pow(*qold, CTRL_BETA2);
+            q11 = o_pow(EEst, beta1);
+            q = q11 / o_pow(*qold, beta2);
             double qg = q / CTRL_GAMMA;
             double lo = 1.0 / CTRL_QMAX, hi = 1.0 / CTRL_QMIN;
             q = (qg < hi) ? qg : hi;

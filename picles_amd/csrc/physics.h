@@ -36,6 +36,8 @@ struct KParams {
     double abstol, reltol, dt0, dtmin;
     long long maxiters;
     int force_dtmin;
+    int solver;              /* 0 DP5, 1 Tsit5 */
+    double beta1, beta2;     /* PI controller exponents of the solver */
     double lne_max, wind_min_sq;
     /* model */
     int init_type;
@@ -78,40 +80,82 @@ struct KParams {
 #define DP_E6 (-22.0 / 525.0)
 #define DP_E7 (1.0 / 40.0)
 
-/* PI controller (OrdinaryDiffEq defaults for DP5) */
+/* PI controller (OrdinaryDiffEq defaults: DP5 beta2 = 4//100, beta1 = 1//5 - 3beta2/4; Tsit5 and
+ * every other order-5 method beta1 = 7//50, beta2 = 2//25) */
 #define PI_BETA1 0.17
 #define PI_BETA2 0.04
+#define PI_BETA1_TSIT 0.14
+#define PI_BETA2_TSIT 0.08
 #define PI_GAMMA 0.9
 #define PI_QMIN 0.2
 #define PI_QMAX 10.0
 #define PI_QOLDINIT 1e-4
 #define PI_LNQOLDINIT (-9.210340371976182) /* ln(1e-4): the carried controller memory is ln(qold) */
 
-/* The 29 tableau constants as one object.  On the device they are read once per thread from
- * LDS into VGPRs before the RK loop: as 64-bit literals they would need 58 SGPRs, overflow the
+/* Tsitouras 5(4) (OrdinaryDiffEq Tsit5; Tsitouras 2011).  The coefficients satisfy all 17 order-5
+ * conditions for b = a7* and the order-4 conditions for b - btilde to 1e-15 (tests/test_tableaux.py). */
+#define TS_C2 0.161
+#define TS_C3 0.327
+#define TS_C4 0.9
+#define TS_C5 0.9800255409045097
+#define TS_A21 0.161
+#define TS_A31 (-0.008480655492356989)
+#define TS_A32 0.335480655492357
+#define TS_A41 2.8971530571054935
+#define TS_A42 (-6.359448489975075)
+#define TS_A43 4.3622954328695815
+#define TS_A51 5.325864828439257
+#define TS_A52 (-11.748883564062828)
+#define TS_A53 7.4955393428898365
+#define TS_A54 (-0.09249506636175525)
+#define TS_A61 5.86145544294642
+#define TS_A62 (-12.92096931784711)
+#define TS_A63 8.159367898576159
+#define TS_A64 (-0.071584973281401)
+#define TS_A65 (-0.028269050394068383)
+#define TS_A71 0.09646076681806523
+#define TS_A72 0.01
+#define TS_A73 0.4798896504144996
+#define TS_A74 1.379008574103742
+#define TS_A75 (-3.290069515436081)
+#define TS_A76 2.324710524099774
+#define TS_E1 (-0.00178001105222577714)
+#define TS_E2 (-0.0008164344596567469)
+#define TS_E3 0.007880878010261995
+#define TS_E4 (-0.1447110071732629)
+#define TS_E5 0.5823571654525552
+#define TS_E6 (-0.45808210592918697)
+#define TS_E7 0.015151515151515152
+
+/* The tableau as one object.  On the device it is read once per thread from LDS into VGPRs
+ * before the RK loop: as 64-bit literals the constants would need > 60 SGPRs, overflow the
  * scalar file and be spilled to VGPR lanes (v_readlane/v_writelane = VALU slots in the hot loop). */
 struct DPTab {
     double a21, a31, a32, a41, a42, a43, a51, a52, a53, a54, a61, a62, a63, a64, a65;
-    double a71, a73, a74, a75, a76, c2, c3, c4, c5, e1, e3, e4, e5, e6, e7;
+    double a71, a72, a73, a74, a75, a76, c2, c3, c4, c5, e1, e2, e3, e4, e5, e6, e7;
 };
-#define DPTAB_INIT                                                                                   \
+#define DPTAB_DP5                                                                                    \
     {DP_A21, DP_A31, DP_A32, DP_A41, DP_A42, DP_A43, DP_A51, DP_A52, DP_A53, DP_A54, DP_A61, DP_A62,  \
-     DP_A63, DP_A64, DP_A65, DP_A71, DP_A73, DP_A74, DP_A75, DP_A76, DP_C2, DP_C3, DP_C4, DP_C5,      \
-     DP_E1, DP_E3, DP_E4, DP_E5, DP_E6, DP_E7}
-#define DPTAB_N 30
+     DP_A63, DP_A64, DP_A65, DP_A71, 0.0, DP_A73, DP_A74, DP_A75, DP_A76, DP_C2, DP_C3, DP_C4, DP_C5, \
+     DP_E1, 0.0, DP_E3, DP_E4, DP_E5, DP_E6, DP_E7}
+#define DPTAB_TSIT5                                                                                  \
+    {TS_A21, TS_A31, TS_A32, TS_A41, TS_A42, TS_A43, TS_A51, TS_A52, TS_A53, TS_A54, TS_A61, TS_A62,  \
+     TS_A63, TS_A64, TS_A65, TS_A71, TS_A72, TS_A73, TS_A74, TS_A75, TS_A76, TS_C2, TS_C3, TS_C4, TS_C5, \
+     TS_E1, TS_E2, TS_E3, TS_E4, TS_E5, TS_E6, TS_E7}
+#define DPTAB_N 32
 
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __constant__ const double DPTAB_C[DPTAB_N] = DPTAB_INIT;
+__device__ __constant__ const double DPTAB_C[2][DPTAB_N] = {DPTAB_DP5, DPTAB_TSIT5};
 __device__ __forceinline__ double *dp_lds_tab(void)
 {
-    __shared__ double tab[32];
+    __shared__ double tab[DPTAB_N];
     return tab;
 }
-__device__ __forceinline__ void dp_device_init(void)   /* call before pm_device_init (shares its barrier) */
+__device__ __forceinline__ void dp_device_init(int solver)   /* call before pm_device_init (shares its barrier) */
 {
-    if (threadIdx.x >= 32 && threadIdx.x < 32 + DPTAB_N) dp_lds_tab()[threadIdx.x - 32] = DPTAB_C[threadIdx.x - 32];
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + DPTAB_N) dp_lds_tab()[threadIdx.x - 32] = DPTAB_C[solver][threadIdx.x - 32];
 }
-__device__ __forceinline__ void dp_load(DPTab &T)
+__device__ __forceinline__ void dp_load(DPTab &T, int)
 {
     const double *t = dp_lds_tab();
     double *o = &T.a21;
@@ -120,12 +164,12 @@ __device__ __forceinline__ void dp_load(DPTab &T)
 }
 #else
 #if defined(__HIPCC__)
-__device__ __forceinline__ void dp_device_init(void) {}
+__device__ __forceinline__ void dp_device_init(int) {}
 #endif
-PM_HD void dp_load(DPTab &T)
+PM_HD void dp_load(DPTab &T, int solver)
 {
-    const DPTab c = DPTAB_INIT;
-    T = c;
+    const DPTab c0 = DPTAB_DP5, c1 = DPTAB_TSIT5;
+    T = solver ? c1 : c0;
 }
 #endif
 
@@ -374,7 +418,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     Vec3 k1, k2, k3, k4, k5, k6, k7;
     WindD W;
     DPTab T;
-    dp_load(T);
+    dp_load(T, P.solver);
+    const bool has2 = (P.solver != 0);   /* Tsit5: a72, e2 != 0 (uniform branch; DP5 arithmetic untouched) */
     double tr = 0.0;
     if (STATIC) wind_derive(w.u0, w.v0, W);
     else wind_stage<false>(P, w, t_start, W);
@@ -403,6 +448,11 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         }
         wind_stage<STATIC>(P, w, PM_FMA(T.c2, h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k2, pc);
+        if (has2) {
+            kx = gx * ipx; ky = gy * ipy;
+            ax = PM_FMA(T.a72, kx, ax); ay = PM_FMA(T.a72, ky, ay);
+            ex = PM_FMA(T.e2, kx, ex); ey = PM_FMA(T.e2, ky, ey);
+        }
 #define ST3(c) PM_FMA(h, PM_FMA(T.a32, k2.c, T.a31 * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
         wind_stage<STATIC>(P, w, PM_FMA(T.c3, h, t), W);
@@ -431,7 +481,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         kx = gx * ipx; ky = gy * ipy;
         ax = PM_FMA(T.a76, kx, ax); ay = PM_FMA(T.a76, ky, ay);
         ex = PM_FMA(T.e6, kx, ex); ey = PM_FMA(T.e6, ky, ey);
-#define ST7(c) PM_FMA(h, PM_FMA(T.a76, k6.c, PM_FMA(T.a75, k5.c, PM_FMA(T.a74, k4.c, PM_FMA(T.a73, k3.c, T.a71 * k1.c)))), z.c)
+#define S72(c) (has2 ? PM_FMA(T.a72, k2.c, T.a71 * k1.c) : T.a71 * k1.c)
+#define ST7(c) PM_FMA(h, PM_FMA(T.a76, k6.c, PM_FMA(T.a75, k5.c, PM_FMA(T.a74, k4.c, PM_FMA(T.a73, k3.c, S72(c))))), z.c)
         Vec5 un;
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax, z.x); un.y = PM_FMA(h, ay, z.y);
@@ -439,7 +490,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         st.rhs += 6;
         kx = un.cx * ipx; ky = un.cy * ipy;
         ex = PM_FMA(T.e7, kx, ex); ey = PM_FMA(T.e7, ky, ey);
-#define ERRC(c) ((h * PM_FMA(T.e7, k7.c, PM_FMA(T.e6, k6.c, PM_FMA(T.e5, k5.c, PM_FMA(T.e4, k4.c, PM_FMA(T.e3, k3.c, T.e1 * k1.c)))))) / \
+#define E12(c) (has2 ? PM_FMA(T.e2, k2.c, T.e1 * k1.c) : T.e1 * k1.c)
+#define ERRC(c) ((h * PM_FMA(T.e7, k7.c, PM_FMA(T.e6, k6.c, PM_FMA(T.e5, k5.c, PM_FMA(T.e4, k4.c, PM_FMA(T.e3, k3.c, E12(c))))))) / \
                  PM_FMA(pm_max(pm_fabs(z.c), pm_fabs(un.c)), P.reltol, P.abstol))
         double EEst = rms5(ERRC(lne), ERRC(cx), ERRC(cy),
                            (h * ex) / PM_FMA(pm_max(pm_fabs(z.x), pm_fabs(un.x)), P.reltol, P.abstol),
@@ -450,6 +502,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #undef ST6
 #undef ST7
 #undef ERRC
+#undef S72
+#undef E12
         if (!(EEst == EEst)) { EEst = pm_inf(); st.status |= 128 /*PICLES_ST_NONFINITE*/; }
         /* PI controller in log space (kernel order): 1/q = γ·qold^β2 / EEst^β1, clamped to
          * [qmin, qmax]; lq = ln(qold) is the carried controller memory. One log + one exp per step. */
@@ -457,7 +511,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         bool accept = (EEst <= 1.0) || (P.force_dtmin && h <= P.dtmin);
         if (accept) {
             st.acc++;
-            double qi = pm_exp(PM_FMA(PI_BETA2, lq, -(PI_BETA1 * le))) * PI_GAMMA;
+            double qi = pm_exp(PM_FMA(P.beta2, lq, -(P.beta1 * le))) * PI_GAMMA;
             qi = (qi > PI_QMAX) ? PI_QMAX : qi;
             qi = (qi < PI_QMIN) ? PI_QMIN : qi;
             lq = (le > PI_LNQOLDINIT) ? le : PI_LNQOLDINIT;
@@ -468,7 +522,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             if (z.lne != z.lne || z.cx != z.cx || z.cy != z.cy || z.x != z.x || z.y != z.y) break;
         } else {
             st.rej++;
-            double r = PI_GAMMA * pm_exp(-(PI_BETA1 * le));
+            double r = PI_GAMMA * pm_exp(-(P.beta1 * le));
             r = (r < PI_QMIN) ? PI_QMIN : r;
             dt = h * r;
             if (!P.force_dtmin && h <= P.dtmin) { st.status |= 64 /*PICLES_ST_DTMIN*/; break; }

@@ -302,7 +302,7 @@ template <bool FAST, bool STATIC, bool METRIC>
 __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
                                                    int r0, int n0, int r1, int n1)
 {
-    dp_device_init();
+    dp_device_init(P.solver);
     pm_device_init();
     long long t = 0;
     bool active = rows_index(G, r0, n0, r1, n1, t);
@@ -474,7 +474,7 @@ template <bool FAST>
 __global__ void __launch_bounds__(256) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
-    dp_device_init();
+    dp_device_init(P.solver);
     pm_device_init();
     long long t = 0;
     bool active = rows_index(G, r0, n0, r1, n1, t);
@@ -847,7 +847,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     *out = nullptr;
     if (g->Nx < 2 || g->Ny < 2) { g_create_error = "grid must be at least 2x2"; return -2; }
     if (g->j_begin < 0 || g->j_end > g->Ny || g->j_end <= g->j_begin) { g_create_error = "bad slab rows [j_begin,j_end)"; return -2; }
-    if (o->solver != 0) { g_create_error = "only solver 0 (DP5) is implemented"; return -3; }
+    if (o->solver != 0 && o->solver != 1) { g_create_error = "solver must be 0 (DP5) or 1 (Tsit5)"; return -3; }
     if (halo_rows < 1) halo_rows = 1;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -879,6 +879,9 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.peak_shift = p->peak_shift; P.direction = p->direction; P.n_is_2 = (P.n == 2.0);
     P.abstol = o->abstol; P.reltol = o->reltol; P.dt0 = o->dt0; P.dtmin = o->dtmin;
     P.maxiters = o->maxiters; P.force_dtmin = o->force_dtmin;
+    P.solver = o->solver;
+    P.beta1 = o->solver ? PI_BETA1_TSIT : PI_BETA1;
+    P.beta2 = o->solver ? PI_BETA2_TSIT : PI_BETA2;
     P.lne_max = o->log_energy_maximum; P.wind_min_sq = o->wind_min_squared;
     P.init_type = m->init_type;
     P.def_lne = m->default_particle[0]; P.def_cx = m->default_particle[1]; P.def_cy = m->default_particle[2];

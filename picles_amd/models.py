@@ -50,12 +50,14 @@ def build_structs(grid: TwoDCartesianGridMesh, ODEsys: ParticleSystem2D, ODEsets
     p.peak_shift, p.direction = int(ODEsys.peak_shift), int(ODEsys.direction)
     p.dir_deadband = float(getattr(ODEsys, "dir_deadband", 0.0))
     o = K.PiclesOde()
-    if ODEsets.solver not in ("DP5",):
-        raise NotImplementedError(f"solver {ODEsets.solver!r}: the kernel implements DP5 (DESIGN.md)")
+    solver = str(ODEsets.solver).replace(" ", "").rstrip("()") if not isinstance(ODEsets.solver, int) else ODEsets.solver
+    solver_id = {"DP5": 0, 0: 0, "Tsit5": 1, 1: 1, "AutoTsit5(Rosenbrock23": 1, "AutoTsit5(Rosenbrock23())": 1}.get(solver)
+    if solver_id is None:
+        raise NotImplementedError(f"solver {ODEsets.solver!r}: the kernels implement DP5 and Tsit5 (DESIGN.md §2)")
     if not ODEsets.adaptive:
         raise NotImplementedError("adaptive=false is not implemented")
     o.abstol, o.reltol, o.dt0, o.dtmin = ODEsets.abstol, ODEsets.reltol, ODEsets.dt, ODEsets.dtmin
-    o.force_dtmin, o.solver, o.maxiters = int(ODEsets.force_dtmin), 0, int(ODEsets.maxiters)
+    o.force_dtmin, o.solver, o.maxiters = int(ODEsets.force_dtmin), solver_id, int(ODEsets.maxiters)
     o.log_energy_minimum, o.log_energy_maximum = ODEsets.log_energy_minimum, ODEsets.log_energy_maximum
     o.wind_min_squared, o.timestep = ODEsets.wind_min_squared, ODEsets.timestep
     m = K.PiclesModel()

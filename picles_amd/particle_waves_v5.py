@@ -59,7 +59,9 @@ def ODEParameters(r_g=0.85, q=-0.25, g=9.81):
 
 @dataclass
 class ODESettings:
-    """particle_waves_v5.jl:34-75 (same field names and defaults; `solver` is a name)"""
+    """particle_waves_v5.jl:34-75 (same field names and defaults; `solver` is the NAME of the
+    OrdinaryDiffEq algorithm: "DP5", "Tsit5", or the reference default "AutoTsit5(Rosenbrock23())",
+    which runs as Tsit5 here — the stiff Rosenbrock23 fallback is not implemented)"""
     Parameters: dict
     log_energy_minimum: float
     saving_step: float
@@ -67,7 +69,7 @@ class ODESettings:
     total_time: float
     log_energy_maximum: float = math.log(17)
     wind_min_squared: float = 4.0
-    solver: str = "DP5"
+    solver: str = "AutoTsit5(Rosenbrock23())"
     abstol: float = 1e-4
     reltol: float = 1e-3
     maxiters: int = int(1e4)
