@@ -36,8 +36,7 @@ struct KParams {
     double abstol, reltol, dt0, dtmin;
     long long maxiters;
     int force_dtmin;
-    int solver;              /* 0 DP5, 1 Tsit5 */
-    double beta1, beta2;     /* PI controller exponents of the solver */
+    int solver;              /* 0 DP5, 1 Tsit5 (selects the kernel instantiation) */
     double lne_max, wind_min_sq;
     /* model */
     int init_type;
@@ -408,7 +407,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
 /* step!(integrator, DT, true): integrate z over [t_start, t_start+DT] with DP5(4).
  * Only the stage derivatives of (lne, c̄x, c̄y) are kept; the x,y rows of the tableau are
  * accumulated as the stages appear (same fma order as the full Butcher sums). */
-template <bool FAST, bool STATIC, bool METRIC = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false>
 PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, double &dtn,
                          double t_start, double DT, PStats &st, double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
 {
@@ -418,8 +417,9 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     Vec3 k1, k2, k3, k4, k5, k6, k7;
     WindD W;
     DPTab T;
-    dp_load(T, P.solver);
-    const bool has2 = (P.solver != 0);   /* Tsit5: a72, e2 != 0 (uniform branch; DP5 arithmetic untouched) */
+    dp_load(T, TSIT ? 1 : 0);
+    constexpr bool has2 = TSIT;   /* Tsit5: a72, e2 != 0 (compile-time: the DP5 instruction stream is untouched) */
+    constexpr double beta1 = TSIT ? PI_BETA1_TSIT : PI_BETA1, beta2 = TSIT ? PI_BETA2_TSIT : PI_BETA2;
     double tr = 0.0;
     if (STATIC) wind_derive(w.u0, w.v0, W);
     else wind_stage<false>(P, w, t_start, W);
@@ -511,7 +511,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         bool accept = (EEst <= 1.0) || (P.force_dtmin && h <= P.dtmin);
         if (accept) {
             st.acc++;
-            double qi = pm_exp(PM_FMA(P.beta2, lq, -(P.beta1 * le))) * PI_GAMMA;
+            double qi = pm_exp(PM_FMA(beta2, lq, -(beta1 * le))) * PI_GAMMA;
             qi = (qi > PI_QMAX) ? PI_QMAX : qi;
             qi = (qi < PI_QMIN) ? PI_QMIN : qi;
             lq = (le > PI_LNQOLDINIT) ? le : PI_LNQOLDINIT;
@@ -522,7 +522,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             if (z.lne != z.lne || z.cx != z.cx || z.cy != z.cy || z.x != z.x || z.y != z.y) break;
         } else {
             st.rej++;
-            double r = PI_GAMMA * pm_exp(-(P.beta1 * le));
+            double r = PI_GAMMA * pm_exp(-(beta1 * le));
             r = (r < PI_QMIN) ? PI_QMIN : r;
             dt = h * r;
             if (!P.force_dtmin && h <= P.dtmin) { st.status |= 64 /*PICLES_ST_DTMIN*/; break; }

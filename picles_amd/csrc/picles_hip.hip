@@ -191,7 +191,7 @@ struct StepStats {
     int reach;
 };
 
-template <bool FAST, bool STATIC, bool METRIC = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false>
 __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
                                                 double &dtn, double t_start, double DT, StepStats &S,
                                                 double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
@@ -199,7 +199,7 @@ __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w,
     int status = PICLES_ST_STEPPED;
     if (on) {
         S.adv = 1;
-        integrate_dp5<FAST, STATIC, METRIC>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc);
+        integrate_dp5<FAST, STATIC, METRIC, TSIT>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc);
         status |= S.st.status;
     } else {
         double u, v;
@@ -298,11 +298,11 @@ __device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r
  * adaptive RK loop runs in registers.  Writes the particle's scatter record instead of
  * scattering: the scatter itself is k_scatter / k_step / k_push_tiles.
  * ---------------------------------------------------------------------------------------- */
-template <bool FAST, bool STATIC, bool METRIC>
+template <bool FAST, bool STATIC, bool METRIC, bool TSIT>
 __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
                                                    int r0, int n0, int r1, int n1)
 {
-    dp_device_init(P.solver);
+    dp_device_init(TSIT ? 1 : 0);
     pm_device_init();
     long long t = 0;
     bool active = rows_index(G, r0, n0, r1, n1, t);
@@ -317,8 +317,8 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         double qold = A.qold[t], dtn = A.dtn[t];
         Wind w = load_wind(P, A, t);
         int status;
-        if (METRIC) status = advance_particle<FAST, STATIC, true>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t]);
-        else status = advance_particle<FAST, STATIC, false>(P, w, z, on, qold, dtn, t_start, DT, S);
+        if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t]);
+        else status = advance_particle<FAST, STATIC, false, TSIT>(P, w, z, on, qold, dtn, t_start, DT, S);
         A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
         A.on[t] = (unsigned char)on;
         A.qold[t] = qold;
@@ -470,11 +470,11 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * stand-alone k_scatter when somebody looks (flush()).  Results are bit-identical to the
  * k_advance + k_scatter sequence.
  * ---------------------------------------------------------------------------------------- */
-template <bool FAST>
+template <bool FAST, bool TSIT>
 __global__ void __launch_bounds__(256) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
-    dp_device_init(P.solver);
+    dp_device_init(TSIT ? 1 : 0);
     pm_device_init();
     long long t = 0;
     bool active = rows_index(G, r0, n0, r1, n1, t);
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(256) k_step(KParams P, GridP G, Arrays A, doub
             if (br == 1) { qold = PI_LNQOLDINIT; S.reseeds = 1; }
             unsigned int rs = S.reseeds;
             S.reseeds = 0;
-            int status = advance_particle<FAST, true>(P, w, z, on, qold, dtn, t_start, DT, S);
+            int status = advance_particle<FAST, true, false, TSIT>(P, w, z, on, qold, dtn, t_start, DT, S);
             S.reseeds += rs;
             A.qold[t] = qold;
             A.status[t] = status;
@@ -880,8 +880,6 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.abstol = o->abstol; P.reltol = o->reltol; P.dt0 = o->dt0; P.dtmin = o->dtmin;
     P.maxiters = o->maxiters; P.force_dtmin = o->force_dtmin;
     P.solver = o->solver;
-    P.beta1 = o->solver ? PI_BETA1_TSIT : PI_BETA1;
-    P.beta2 = o->solver ? PI_BETA2_TSIT : PI_BETA2;
     P.lne_max = o->log_energy_maximum; P.wind_min_sq = o->wind_min_squared;
     P.init_type = m->init_type;
     P.def_lne = m->default_particle[0]; P.def_cx = m->default_particle[1]; P.def_cy = m->default_particle[2];
@@ -1215,12 +1213,15 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
         bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
         dim3 grid(nblocks(nt, 256)), block(256);
         Arrays A = arrays_for(c, c->cur, c->cur);
-#define LAUNCH_ADV(F, S, M) hipLaunchKernelGGL((k_advance<F, S, M>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1)
+#define LAUNCH_ADV2(F, S, M) do { if (P.solver) hipLaunchKernelGGL((k_advance<F, S, M, true>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); \
+                                   else hipLaunchKernelGGL((k_advance<F, S, M, false>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); } while (0)
+#define LAUNCH_ADV(F, S, M) LAUNCH_ADV2(F, S, M)
         if (c->A.pc) LAUNCH_ADV(false, false, true);   /* per-node metric: the general code path */
         else if (fast && P.wind_static) LAUNCH_ADV(true, true, false);
         else if (fast) LAUNCH_ADV(true, false, false);
         else if (P.wind_static) LAUNCH_ADV(false, true, false);
         else LAUNCH_ADV(false, false, false);
+#undef LAUNCH_ADV2
 #undef LAUNCH_ADV
     }
     timing_end(c, s);
@@ -1253,8 +1254,12 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
     dim3 grid(nblocks(nt, 256)), block(256);
     timing_begin(c, s, 0);
-    if (fast) hipLaunchKernelGGL((k_step<true>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1);
-    else hipLaunchKernelGGL((k_step<false>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1);
+#define LAUNCH_STEP(F, T) hipLaunchKernelGGL((k_step<F, T>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
+    if (fast && P.solver) LAUNCH_STEP(true, true);
+    else if (fast) LAUNCH_STEP(true, false);
+    else if (P.solver) LAUNCH_STEP(false, true);
+    else LAUNCH_STEP(false, false);
+#undef LAUNCH_STEP
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
     return 0;
