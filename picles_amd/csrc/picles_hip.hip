@@ -283,10 +283,23 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
     }
 }
 
+/* XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8),
+ * each with its own L2.  The pull scatter of a node reads the records of the rows above and below,
+ * so vertically adjacent 256-node segments should share an L2: give every XCD one contiguous band
+ * of the index space (logical block = (b % 8) * ceil(n/8) + b / 8).  Placement is a speed matter only. */
+__device__ __forceinline__ unsigned int xcd_block(void)
+{
+    const unsigned int n = gridDim.x, b = blockIdx.x;
+    const unsigned int per = (n + 7u) / 8u;
+    unsigned int l = (b % 8u) * per + b / 8u;
+    /* grids that are not a multiple of 8: the tail of the last bands is empty; fall back to identity there */
+    return (n % 8u == 0u) ? l : b;
+}
+
 /* local rows [r0, r0+n0) ∪ [r1, r1+n1) -> particle index */
 __device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r1, int n1, long long &t)
 {
-    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tid = (long long)xcd_block() * blockDim.x + threadIdx.x;
     long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
     if (tid >= na + nb) return false;
     t = (tid < na) ? (long long)r0 * G.Nx + tid : (long long)r1 * G.Nx + (tid - na);
@@ -431,7 +444,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
                                                    double clock, double DT)
 {
     if (REMESH) pm_device_init();
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long t = (long long)xcd_block() * blockDim.x + threadIdx.x;
     unsigned int reseeds = 0;
     if (t < A.n) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
