@@ -260,3 +260,20 @@ def test_run_with_async_state_store(tmp_path):
     assert data.shape[0] >= 14 and len(sim2.store.store) == 14
     for k in range(14):
         assert np.array_equal(data[k], sim2.store.store[k]), k
+
+
+def test_plain_c_host_program(tmp_path):
+    """the drop-in boundary used from C with nothing but include/picles_hip.h and the shared library"""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "minimal_c_abi"
+    lib = root / "picles_amd" / "csrc"
+    subprocess.run(["gcc", "-O2", "-I", str(root / "include"), str(root / "examples" / "minimal_c_abi.c"), "-o", str(exe),
+                    "-L", str(lib), "-lpicles_hip", f"-Wl,-rpath,{lib}", "-lm"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "clock 7800 s" in out
+    hs = float(out.split("Hs(centre) = ")[1].split(" m")[0])
+    # same scenario through the Python host layer
+    m, S = run_states(configs.example_00_minimal(), "hip", 13)
+    assert hs == pytest.approx(4 * np.sqrt(S[13][25, 25, 0]), rel=1e-6)

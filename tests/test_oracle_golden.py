@@ -112,3 +112,20 @@ def test_orders_agree_at_tolerance_level():
     _, B = run_states(cfg, ("pmath", 1), 8)
     a, b = A[-1][..., 0], B[-1][..., 0]
     assert np.nanmax(np.abs(a - b) / np.maximum(np.abs(a), 1e-30)) < 5e-3
+
+
+STATE_FIX = np.load(Path(__file__).parent / "golden" / "example00_21x21_states.npz")
+
+
+@pytest.mark.parametrize("solver", ["DP5", "Tsit5"])
+@pytest.mark.parametrize("backend", [("libm", 0), ("pmath", 1), pytest.param("hip", marks=pytest.mark.gpu)])
+def test_state_regression_fixture(solver, backend):
+    """committed State snapshots (oracle A) of the example_00 scenario on 21×21: any backend must stay
+    within 1e-9 relative (C_phi = 1.81e-5: not stiff, orders and math back-ends agree to ~1e-13)"""
+    cfg = configs.example_00_minimal(n=21, L=40e3)
+    cfg.model["ODEsets"].solver = solver
+    _, S = run_states(cfg, backend, 13)
+    for k in (1, 6, 13):
+        ref = STATE_FIX[f"{solver}_step{k}"]
+        scale = np.abs(ref).max(axis=(0, 1), keepdims=True)
+        assert np.abs(S[k] - ref).max() <= 1e-9 * scale.max(), (solver, k, np.abs(S[k] - ref).max())
