@@ -8,7 +8,7 @@ import pytest
 from picles_amd import configs, _capi as K
 from picles_amd.grids import TwoDCartesianGridMesh
 from picles_amd.simulations import Simulation, initialize_simulation
-from picles_amd.timesteppers import time_step, time_step_advance, time_step_remesh
+from picles_amd.timesteppers import time_step, time_step_advance, time_step_remesh, movie_time_step
 from helpers import make_model, run_states, assert_bitwise
 
 pytestmark = pytest.mark.gpu
@@ -277,3 +277,36 @@ def test_plain_c_host_program(tmp_path):
     # same scenario through the Python host layer
     m, S = run_states(configs.example_00_minimal(), "hip", 13)
     assert hs == pytest.approx(4 * np.sqrt(S[13][25, 25, 0]), rel=1e-6)
+
+
+def test_mixed_call_sequences_keep_parity():
+    """fused run!-style steps interleaved with observers, movie steps, split calls, particle edits and a
+    changing Δt: the lazily flushed scatter+remesh must never be observable (bitwise vs the oracle)."""
+    fn = lambda: configs.bench06_box(n=40)
+    g, o = _pair(fn)
+    for m in (g, o):
+        _init(m, 600.0)
+
+    def both(f):
+        for m in (g, o):
+            f(m)
+
+    both(lambda m: [time_step(m, 600.0, zero_first=True) for _ in range(3)])          # fused, fused, fused
+    assert_bitwise(g.State, o.State, "after 3 fused steps")                              # observer -> flush
+    both(lambda m: [time_step(m, 300.0, zero_first=True) for _ in range(2)])          # different Δt
+    both(lambda m: movie_time_step(m, 600.0))                                            # unfused (movie)
+    assert_bitwise(g.MovieState, o.MovieState, "movie state")
+    both(lambda m: time_step(m, 600.0, zero_first=True))
+    _same_particles(g, o)                                                                 # particles observed mid-sequence
+    z, on, _, _ = o.backend.get_particles()
+    z = z.copy(); z[7, 9, 0] -= 0.5
+    both(lambda m: m.backend.set_particles(z, on))                                       # edit between fused steps
+    both(lambda m: [time_step(m, 600.0, zero_first=True) for _ in range(2)])
+    both(lambda m: (m.backend.zero_state(), time_step_advance(m, 600.0)))                # split API after fused steps
+    assert_bitwise(g.State, o.State, "after split advance")
+    both(lambda m: (time_step_remesh(m, 600.0), m.backend.tick(600.0)))
+    both(lambda m: time_step(m, 600.0, zero_first=False))                               # accumulate onto existing State
+    assert_bitwise(g.State, o.State, "accumulating step")
+    cg, co = g.backend.get_counters(), o.backend.get_counters()
+    for k in ("rhs_evals", "steps_accepted", "reseeds", "particles_advanced"):
+        assert cg[k] == co[k], k
