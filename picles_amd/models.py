@@ -173,10 +173,13 @@ class WaveGrowth2D:
             return
         if self._wind_window == (t, t + dt):
             return
-        u0, v0 = sample_winds(self.winds, self.grid, t)
+        # the level sampled for the end of the previous step is the start level of this one
+        last = getattr(self, "_wind_last", None)
+        u0, v0 = (last[1], last[2]) if last is not None and last[0] == t else sample_winds(self.winds, self.grid, t)
         u1, v1 = sample_winds(self.winds, self.grid, t + dt)
         self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
         self._wind_window = (t, t + dt)
+        self._wind_last = (t + dt, u1, v1)
 
     # ---- State lives on the device ----
     @property

@@ -183,9 +183,11 @@ class SlabModel:
                 self.backend.set_winds(u, v, t)
                 self._wind_window = (t, t)
             return
-        u0, v0 = sample_winds(self.winds, self.grid, t, rows)
+        last = getattr(self, "_wind_last", None)
+        u0, v0 = (last[1], last[2]) if last is not None and last[0] == t else sample_winds(self.winds, self.grid, t, rows)
         u1, v1 = sample_winds(self.winds, self.grid, t + dt, rows)
         self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
+        self._wind_last = (t + dt, u1, v1)
 
     def seed(self):
         self._wind_window = None
