@@ -344,7 +344,7 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
         else
             s2 = ((2.0 * crs) * dot) * (rc2 * W.invU2);
         /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned */
-        if (P.deadband2 > 0.0 && crs * crs <= P.deadband2 * (W.U2 * (cgp * cgp))) s2 = 0.0;
+        if (!FAST && P.deadband2 > 0.0 && crs * crs <= P.deadband2 * (W.U2 * (cgp * cgp))) s2 = 0.0;   /* FAST kernels are only selected with the dead band off */
         Sd = (((alpha * alpha) * P.C_phi) * H) * s2;
     }
     double wrS = (wp * P.r_g) * Scg;

@@ -1223,7 +1223,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     timing_begin(c, s, 0);
     {
         const KParams &P = c->P;
-        bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+        bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
         dim3 grid(nblocks(nt, 256)), block(256);
         Arrays A = arrays_for(c, c->cur, c->cur);
 #define LAUNCH_ADV2(F, S, M) do { if (P.solver) hipLaunchKernelGGL((k_advance<F, S, M, true>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); \
@@ -1264,7 +1264,7 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     if ((rc = step_prologue(c, s))) return rc;
     const KParams &P = c->P;
     Arrays A = arrays_for(c, c->cur ^ 1, c->cur);
-    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
     dim3 grid(nblocks(nt, 256)), block(256);
     timing_begin(c, s, 0);
 #define LAUNCH_STEP(F, T) hipLaunchKernelGGL((k_step<F, T>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
