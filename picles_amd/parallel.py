@@ -194,6 +194,15 @@ class SlabModel:
         self.upload_winds(0.0, self.timestep)
         self.backend.seed(0.0)
         self.backend.sync()        # the seed kernel runs on the context stream, the steps on s_edge / s_main
+        if self.ex is not None and not getattr(self, "_comm_warm", False):
+            # one throw-away exchange: RCCL builds its P2P channels lazily on first use — keep that
+            # out of the first model step (the ghost rows are rewritten by every real exchange)
+            self.ex.finish(self.ex.start())
+            if self.use_streams:
+                self.ex.torch.cuda.synchronize()
+            self._comm_warm = True
+            self.backend.seed(0.0)   # restore the zero ghost rows / records the exchange touched
+            self.backend.sync()
         self.clock = 0.0
 
     def time_step(self, dt, flags=K.STEP_ZERO_FIRST):
