@@ -155,6 +155,9 @@ int32_t picles_seed(picles_ctx *ctx, double t0);
 
 /* time_step!(model, Δt) / movie_time_step! (TimeSteppers.jl:109-166,212-247) */
 int32_t picles_time_step(picles_ctx *ctx, double dt, int32_t flags);
+/* n consecutive run!-style steps (State .= 0; time_step!) enqueued back to back from C: the loop of
+ * run! (run.jl:72-114) when nothing observes State between the steps.  Asynchronous like picles_time_step. */
+int32_t picles_run_steps(picles_ctx *ctx, double dt, int32_t n_steps);
 /* time_step!_advance / time_step!_remesh (TimeSteppers.jl:168-193); remesh does NOT tick */
 int32_t picles_advance(picles_ctx *ctx, double dt, int32_t flags);
 int32_t picles_remesh(picles_ctx *ctx, double dt);

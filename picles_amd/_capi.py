@@ -109,6 +109,7 @@ SYMBOLS = {
     "picles_get_winds": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p, c_double_p]),
     "picles_seed": (C.c_int32, [_VP, C.c_double]),
     "picles_time_step": (C.c_int32, [_VP, C.c_double, C.c_int32]),
+    "picles_run_steps": (C.c_int32, [_VP, C.c_double, C.c_int32]),
     "picles_advance": (C.c_int32, [_VP, C.c_double, C.c_int32]),
     "picles_remesh": (C.c_int32, [_VP, C.c_double]),
     "picles_tick": (C.c_int32, [_VP, C.c_double]),

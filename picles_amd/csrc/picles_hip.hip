@@ -1388,6 +1388,16 @@ PX_EXPORT int32_t picles_time_step(picles_ctx *c, double dt, int32_t flags)
     return picles_scatter_remesh(c, nullptr);
 }
 
+PX_EXPORT int32_t picles_run_steps(picles_ctx *c, double dt, int32_t n_steps)
+{
+    if (!c || n_steps < 0) return -1;
+    for (int k = 0; k < n_steps; k++) {
+        int rc = picles_time_step(c, dt, PICLES_STEP_ZERO_FIRST);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 PX_EXPORT int32_t picles_advance(picles_ctx *c, double dt, int32_t flags)
 {
     if (!c) return -1;

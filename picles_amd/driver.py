@@ -95,6 +95,9 @@ class HipModel:
     def time_step(self, dt, flags=0):
         self._ck(self.lib.picles_time_step(self.h, dt, flags), "picles_time_step")
 
+    def run_steps(self, dt, n):
+        self._ck(self.lib.picles_run_steps(self.h, dt, n), "picles_run_steps")
+
     def advance(self, dt, flags=0):
         self._ck(self.lib.picles_advance(self.h, dt, flags), "picles_advance")
 

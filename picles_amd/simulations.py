@@ -106,6 +106,18 @@ def run(sim: Simulation, store=False, pickup=False, cash_store=False, debug=Fals
         if ring and not getattr(sim.model.backend, "_store_ready", False):
             sim.model.backend.store_init(3)
             sim.model.backend._store_ready = True
+    m = sim.model
+    if (not store and not cash_store and hasattr(m.backend, "run_steps") and getattr(m, "_winds_static", False)
+            and sim.stop_time != float("inf")):
+        # nothing observes State between the steps: enqueue the whole loop from C in one call
+        import math
+        n = int(math.floor((sim.stop_time - m.clock.time) / sim.Δt)) + 1 if sim.running else 0   # run.jl:113: one step past stop_time
+        if n > 0:
+            m.upload_winds(m.clock.time, sim.Δt)
+            m.backend.run_steps(sim.Δt, n)
+            m.clock.time += n * sim.Δt
+            m.clock.iteration += n
+        sim.running = False
     while sim.running:
         # State .= 0 is fused into the scatter kernel (zero_first)
         time_step(sim.model, sim.Δt, debug=debug, zero_first=True)

@@ -310,3 +310,15 @@ def test_mixed_call_sequences_keep_parity():
     cg, co = g.backend.get_counters(), o.backend.get_counters()
     for k in ("rhs_evals", "steps_accepted", "reseeds", "particles_advanced"):
         assert cg[k] == co[k], k
+
+
+def test_run_without_observers_uses_one_call_and_matches_stepwise():
+    from picles_amd.simulations import run
+    a = make_model(configs.example_00_minimal(), "hip")
+    sa = Simulation(a, Δt=600.0, stop_time=7200.0)
+    run(sa)                                            # picles_run_steps: 13 steps enqueued from C
+    b = make_model(configs.example_00_minimal(), "hip")
+    sb = Simulation(b, Δt=600.0, stop_time=7200.0)
+    run(sb, cash_store=True)                           # step by step with snapshots
+    assert a.clock.time == b.clock.time == 13 * 600.0 and a.clock.iteration == 13
+    assert np.array_equal(a.State, sb.store.store[-1])
