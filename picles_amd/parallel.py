@@ -155,6 +155,8 @@ class SlabModel:
             self.backend = HipModel(g, p, o, m, mask=grid.data.mask, device=device, halo_rows=halo_rows)
         else:
             self.backend = backend_factory(g, p, o, m, grid.data.mask, halo_rows=halo_rows)
+        if hasattr(grid, "metric"):     # spherical mesh: per-node projection + great-circle term, own rows
+            self.backend.set_metric(*[a[:, self.j0:self.j1] for a in grid.metric()])
         self.static = bool(cfg_model.get("winds_static", False))
         self.timestep = ODEsets.timestep
         self.clock = 0.0

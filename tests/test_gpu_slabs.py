@@ -24,7 +24,9 @@ def _cfg(name):
     from picles_amd import configs
     return {"periodic": lambda: configs.bench06_box(n=64, dx=1500.0),
             "nonperiodic_generic": lambda: configs.T04_2D_reg_test(U10=10.0, V10=3.0, periodic=False, n=45, L=176e3),
-            "calm": lambda: configs.growing_decaying_winds(n=48)}[name]()
+            "calm": lambda: configs.growing_decaying_winds(n=48),
+            "periodic_model_ring": lambda: configs.T04_2D_reg_test(U10=-10.0, V10=10.0, periodic=True, n=45, L=176e3),
+            "sphere": lambda: configs.sphere_aqua(nx=46, ny=45, n_steps=4)}[name]()
 
 
 def _worker(rank, world, port, name, n_steps, halo, outdir):
@@ -46,7 +48,8 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world,halo", [("periodic", 2, 1), ("periodic", 3, 2), ("nonperiodic_generic", 2, 1), ("calm", 2, 2)])
+@pytest.mark.parametrize("name,world,halo", [("periodic", 2, 1), ("periodic", 3, 2), ("nonperiodic_generic", 2, 1), ("calm", 2, 2),
+                                             ("periodic_model_ring", 3, 1), ("sphere", 2, 2)])
 def test_gpu_slabs_equal_single_context(tmp_path, name, world, halo):
     from picles_amd.parallel import SlabModel
     n_steps = 4
