@@ -260,23 +260,32 @@ __device__ __forceinline__ void write_record(const GridP &G, const Arrays &A, in
     rr[5 * G.Nx + i] = code;
 }
 
-/* statistics: wave-reduce, one atomic per wave into the wave's slot */
+/* statistics: one atomic per wave into the wave's slot.  The 0/1 flags are counted with a ballot +
+ * scalar popcount (no cross-lane traffic), the step counters with two 64-bit butterfly sums
+ * (accepted and rejected steps share one word), the reach with a ballot ladder. */
 __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
 {
-    unsigned long long s_rhs = wave_sum_u64(S.st.rhs), s_acc = wave_sum_u64(S.st.acc), s_rej = wave_sum_u64(S.st.rej);
-    unsigned long long s_adv = wave_sum_u64(S.adv), s_res = wave_sum_u64(S.reseeds), s_cl = wave_sum_u64(S.clamps);
-    unsigned long long s_mx = wave_sum_u64(S.maxit), s_ov = wave_sum_u64(S.overflow);
-    int m_reach = wave_max_i32(S.reach);
+    unsigned long long s_rhs = wave_sum_u64(S.st.rhs);
+    unsigned long long s_ar = wave_sum_u64(((unsigned long long)S.st.acc << 32) | S.st.rej);
+    unsigned long long b_adv = __ballot(S.adv != 0), b_res1 = __ballot(S.reseeds == 1), b_res2 = __ballot(S.reseeds >= 2);
+    unsigned long long b_cl = __ballot(S.clamps != 0), b_mx = __ballot(S.maxit != 0), b_ov = __ballot(S.overflow != 0);
+    int m_reach = 0;
+    if (__ballot(S.reach > 0)) {
+        m_reach = 1;
+        while (__ballot(S.reach > m_reach)) m_reach++;   /* reach is 1 in all but exotic steps: one extra ballot */
+    }
     if ((threadIdx.x & 63) == 0) {
         DevCounters *c = A.cnt + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (NSLOTS - 1));
+        unsigned long long s_acc = s_ar >> 32, s_rej = s_ar & 0xffffffffULL;
+        unsigned long long s_res = (unsigned long long)__popcll(b_res1) + 2ull * __popcll(b_res2);
         if (s_rhs) atomicAdd(&c->rhs, s_rhs);
         if (s_acc) atomicAdd(&c->acc, s_acc);
         if (s_rej) atomicAdd(&c->rej, s_rej);
-        if (s_adv) atomicAdd(&c->adv, s_adv);
+        if (b_adv) atomicAdd(&c->adv, (unsigned long long)__popcll(b_adv));
         if (s_res) atomicAdd(&c->reseeds, s_res);
-        if (s_cl) atomicAdd(&c->clamps, s_cl);
-        if (s_mx) atomicAdd(&c->maxit, s_mx);
-        if (s_ov) atomicAdd(&c->overflow, s_ov);
+        if (b_cl) atomicAdd(&c->clamps, (unsigned long long)__popcll(b_cl));
+        if (b_mx) atomicAdd(&c->maxit, (unsigned long long)__popcll(b_mx));
+        if (b_ov) atomicAdd(&c->overflow, (unsigned long long)__popcll(b_ov));
         /* one address for the whole grid: only waves that would raise it touch it */
         if (m_reach > __hip_atomic_load(A.max_reach_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(A.max_reach_out, m_reach);
