@@ -428,8 +428,14 @@ static double po_initdt(const po_model *M, int64_t idx, const double u0[5], cons
     int K = M->order;
     for (int i = 0; i < 5; i++) {
         sk[i] = K ? PO_FMA(fabs(u0[i]), od->reltol, od->abstol) : od->abstol + fabs(u0[i]) * od->reltol;
-        a0[i] = u0[i] / sk[i];
-        a1[i] = f0[i] / sk[i];
+        if (K) {   /* kernel order: one reciprocal per component, the norms multiply by it */
+            sk[i] = 1.0 / sk[i];
+            a0[i] = u0[i] * sk[i];
+            a1[i] = f0[i] * sk[i];
+        } else {
+            a0[i] = u0[i] / sk[i];
+            a1[i] = f0[i] / sk[i];
+        }
     }
     double d0 = K ? po_norm5_k(a0) : po_norm5_lit(a0);
     double d1 = K ? po_norm5_k(a1) : po_norm5_lit(a1);
@@ -442,7 +448,7 @@ static double po_initdt(const po_model *M, int64_t idx, const double u0[5], cons
     po_wind(M, idx, t + dt0, &uw, &vw);
     po_rhs(M, idx, u1, uw, vw, f1);
     st->rhs++;
-    for (int i = 0; i < 5; i++) a1[i] = (f1[i] - f0[i]) / sk[i];
+    for (int i = 0; i < 5; i++) a1[i] = K ? (f1[i] - f0[i]) * sk[i] : (f1[i] - f0[i]) / sk[i];
     double d2 = (K ? po_norm5_k(a1) : po_norm5_lit(a1)) / dt0;
     double m = (d1 > d2) ? d1 : d2;
     double dt1;

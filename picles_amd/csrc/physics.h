@@ -370,13 +370,14 @@ template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, const Vec3 &k1, double kx, double ky,
                      double ipx, double ipy, double pc, double t, PStats &st)
 {
-    double sk0 = PM_FMA(pm_fabs(u0.lne), P.reltol, P.abstol);
-    double sk1 = PM_FMA(pm_fabs(u0.cx), P.reltol, P.abstol);
-    double sk2 = PM_FMA(pm_fabs(u0.cy), P.reltol, P.abstol);
-    double sk3 = PM_FMA(pm_fabs(u0.x), P.reltol, P.abstol);
-    double sk4 = PM_FMA(pm_fabs(u0.y), P.reltol, P.abstol);
-    double d0 = rms5(u0.lne / sk0, u0.cx / sk1, u0.cy / sk2, u0.x / sk3, u0.y / sk4);
-    double d1 = rms5(k1.lne / sk0, k1.cx / sk1, k1.cy / sk2, kx / sk3, ky / sk4);
+    /* 1/sk once per component (kernel order): the three norms multiply by it */
+    double r0 = 1.0 / PM_FMA(pm_fabs(u0.lne), P.reltol, P.abstol);
+    double r1 = 1.0 / PM_FMA(pm_fabs(u0.cx), P.reltol, P.abstol);
+    double r2 = 1.0 / PM_FMA(pm_fabs(u0.cy), P.reltol, P.abstol);
+    double r3 = 1.0 / PM_FMA(pm_fabs(u0.x), P.reltol, P.abstol);
+    double r4 = 1.0 / PM_FMA(pm_fabs(u0.y), P.reltol, P.abstol);
+    double d0 = rms5(u0.lne * r0, u0.cx * r1, u0.cy * r2, u0.x * r3, u0.y * r4);
+    double d1 = rms5(k1.lne * r0, k1.cx * r1, k1.cy * r2, kx * r3, ky * r4);
     double dt0;
     if (d0 < 1e-5 || d1 < 1e-5) dt0 = 1e-6;
     else dt0 = 0.01 * (d0 / d1);
@@ -387,8 +388,8 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
     rhs3<FAST, METRIC>(P, l1, cx1, cy1, W, f1, pc);
     st.rhs++;
     double f1x = cx1 * ipx, f1y = cy1 * ipy;
-    double d2 = rms5((f1.lne - k1.lne) / sk0, (f1.cx - k1.cx) / sk1, (f1.cy - k1.cy) / sk2,
-                     (f1x - kx) / sk3, (f1y - ky) / sk4) / dt0;
+    double d2 = rms5((f1.lne - k1.lne) * r0, (f1.cx - k1.cx) * r1, (f1.cy - k1.cy) * r2,
+                     (f1x - kx) * r3, (f1y - ky) * r4) / dt0;
     double m = (d1 > d2) ? d1 : d2;
     double dt1;
     if (m <= 1e-15) {
