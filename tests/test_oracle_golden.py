@@ -129,3 +129,16 @@ def test_state_regression_fixture(solver, backend):
         ref = STATE_FIX[f"{solver}_step{k}"]
         scale = np.abs(ref).max(axis=(0, 1), keepdims=True)
         assert np.abs(S[k] - ref).max() <= 1e-9 * scale.max(), (solver, k, np.abs(S[k] - ref).max())
+
+
+def test_fully_developed_sea_limit():
+    """physical sanity pin that needs no oracle of the oracle: under a constant 14.1 m/s wind the
+    homogeneous periodic box saturates at the fully developed sea; Pierson–Moskowitz gives Hs = 0.0246 U² (the
+    reference quotes the same law, FetchRelations.jl:337-339)."""
+    cfg = configs.bench06_box(n=8)
+    m, S = run_states(cfg, ("libm", 0), 400)
+    hs = 4 * np.sqrt(S[-1][3, 3, 0])
+    U = np.hypot(10.0, 10.0)
+    assert abs(hs - 0.0246 * U ** 2) < 0.1 * 0.0246 * U ** 2
+    # and it has converged: the last 50 steps change Hs by less than 0.5 %
+    assert abs(4 * np.sqrt(S[-50][3, 3, 0]) / hs - 1) < 5e-3
