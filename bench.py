@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid-n", dest="n", type=int, default=4096, help="grid nodes per side")
     ap.add_argument("--winds", type=lambda s: tuple(float(x) for x in s.split(",")), default=(10.0, 10.0))
-    ap.add_argument("--halo", type=int, default=1, help="halo rows / pull reach for slabs")
+    ap.add_argument("--halo", type=int, default=2,
+                    help="halo rows = scatter reach the slabs cover (the box reaches 2 cells after ~45 steps; ignored for one GPU)")
     ap.add_argument("--atomic", action="store_true", help="LDS-tiled atomic push scatter instead of the pull")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
