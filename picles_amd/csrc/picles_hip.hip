@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
         int R = G.Rp;
         if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
         if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
+        else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
         else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
         if (movie) {
             A.movie[t] = s0; A.movie[t + A.n] = s1; A.movie[t + 2 * A.n] = s2;
@@ -507,6 +508,7 @@ __global__ void __launch_bounds__(256) k_step(KParams P, GridP G, Arrays A, doub
         int R = G.Rp;
         if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
         if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
+        else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
         else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
         A.state[t] = s0; A.state[t + A.n] = s1; A.state[t + 2 * A.n] = s2;
         unsigned char pf = A.pflags[t];
