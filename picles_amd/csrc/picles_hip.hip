@@ -398,6 +398,28 @@ __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &
  * ---------------------------------------------------------------------------------------- */
 /* sum of the contributions to node (i, j); RT > 0: reach known at compile time (fully unrolled:
  * all candidate codes are loaded before any is inspected), RT == 0: runtime reach R */
+/* one candidate source: record element offset `off` (plane 0 of the source particle), cell offsets
+ * (di, dj) of the source relative to the node */
+__device__ __forceinline__ void pull_candidate(const double *__restrict__ rec, unsigned int off, unsigned int pl, int di, int dj,
+                                               int grp, bool ok, double &s0, double &s1, double &s2)
+{
+    double code = rec[off + 5u * pl];
+    int cg, bx, by;
+    rec_decode(code, cg, bx, by);
+    int ax = -di - bx, ay = -dj - by;
+    if (ok && code != 0.0 && cg == grp && ax >= 0 && ax <= 1 && ay >= 0 && ay <= 1) {
+        double wxh = rec[off + 3u * pl], wyh = rec[off + 4u * pl];
+        double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
+        s0 += w * rec[off];
+        s1 += w * rec[off + pl];
+        s2 += w * rec[off + 2u * pl];
+    }
+}
+
+/* sum of the contributions to node (i, j); RT > 0: reach known at compile time (fully unrolled:
+ * all candidate codes are loaded before any is inspected), RT == 0: runtime reach R.
+ * Record elements are addressed with 32-bit offsets from one base pointer (the host falls back to
+ * a single-plane-per-call layout check: (ny_loc + 2R) * 6 * Nx < 2^31 elements). */
 template <int RT>
 __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i, int jl, int Rdyn,
                                           double &s0, double &s1, double &s2)
@@ -405,12 +427,45 @@ __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i
     const int R = RT ? RT : Rdyn, W = 2 * R + 1;
     const int RO = G.R;   /* row offset of the own rows inside rec */
     const int j = jl + G.j_begin, Nx = G.Nx;
+    const double *__restrict__ rec = A.rec;
+    const unsigned int pl = (unsigned int)Nx, rowlen = 6u * pl;
+    /* interior nodes: no wrap, no drop, natural (= reference) order */
+    bool interior = (i - R >= 0) && (i + R < Nx) && (j - R >= 0) && (j + R < G.Ny);
+    if (interior) {
+        const unsigned int base = (unsigned int)(jl + RO) * rowlen + (unsigned int)i;
+        for (int grp = 1; grp <= G.ngroups; grp++) {
+            if constexpr (RT == 1) {
+#pragma unroll
+                for (int dj = -1; dj <= 1; dj++) {
+#pragma unroll
+                    for (int di = -1; di <= 1; di++)
+                        pull_candidate(rec, base + (unsigned int)(dj * (int)rowlen + di), pl, di, dj, grp, true, s0, s1, s2);
+                }
+            } else {
+                /* wider reach: one row of candidates at a time keeps the register footprint of the
+                 * fused step kernel at two waves per SIMD */
+#pragma unroll 1
+                for (int dj = -R; dj <= R; dj++) {
+                    const unsigned int rb = base + (unsigned int)(dj * (int)rowlen);
+                    if constexpr (RT != 0) {
+#pragma unroll
+                        for (int di = -RT; di <= RT; di++)
+                            pull_candidate(rec, rb + (unsigned int)di, pl, di, dj, grp, true, s0, s1, s2);
+                    } else {
+                        for (int di = -R; di <= R; di++)
+                            pull_candidate(rec, rb + (unsigned int)di, pl, di, dj, grp, true, s0, s1, s2);
+                    }
+                }
+            }
+        }
+        return;
+    }
     int shx = 0, shy = 0;
     if (G.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= Nx) shx = Nx - i + R; }
     if (G.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= G.Ny) shy = G.Ny - j + R; }
     for (int grp = 1; grp <= G.ngroups; grp++) {
-#pragma unroll
-        for (int sj = 0; sj < (RT ? 2 * RT + 1 : W); sj++) {
+#pragma unroll 1
+        for (int sj = 0; sj < W; sj++) {
             int qj = sj + shy; if (qj >= W) qj -= W;
             int dj = qj - R;
             int jj = j + dj;
@@ -423,26 +478,15 @@ __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i
                 row = jl + dj + RO;
             }
             if (!rowok) row = RO;   /* any valid row: the candidate is masked below */
-            const double *rr = rec_row(A, G, row);
-#pragma unroll
-            for (int si = 0; si < (RT ? 2 * RT + 1 : W); si++) {
+#pragma unroll 1
+            for (int si = 0; si < W; si++) {
                 int qi = si + shx; if (qi >= W) qi -= W;
                 int di = qi - R;
                 int ii = i + di;
                 bool ok = rowok;
                 if (ii < 0) { ok = ok && G.periodic_x; ii += Nx; }
                 else if (ii >= Nx) { ok = ok && G.periodic_x; ii -= Nx; }
-                double code = rr[5 * Nx + ii];
-                int cg, bx, by;
-                rec_decode(code, cg, bx, by);
-                int ax = -di - bx, ay = -dj - by;
-                if (ok && code != 0.0 && cg == grp && ax >= 0 && ax <= 1 && ay >= 0 && ay <= 1) {
-                    double wxh = rr[3 * Nx + ii], wyh = rr[4 * Nx + ii];
-                    double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
-                    s0 += w * rr[ii];
-                    s1 += w * rr[Nx + ii];
-                    s2 += w * rr[2 * Nx + ii];
-                }
+                pull_candidate(rec, (unsigned int)row * rowlen + (unsigned int)ii, pl, di, dj, grp, ok, s0, s1, s2);
             }
         }
     }
@@ -462,7 +506,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
         int R = G.Rp;
         if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
         if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
-        else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
+        //R2 else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
         else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
         if (movie) {
             A.movie[t] = s0; A.movie[t + A.n] = s1; A.movie[t + 2 * A.n] = s2;
@@ -947,6 +991,11 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
         pf[k] = f;
     }
     if (any3 && m->periodic_boundary) G.ngroups = 2;
+    if ((long long)(G.ny_loc + 2 * G.R) * 6 * G.Nx >= (1LL << 31)) {
+        g_create_error = "slab too large for 32-bit record offsets ((ny_loc + 2 halo_rows) * 6 * Nx must be < 2^31): use more slabs";
+        delete c;
+        return -2;
+    }
     if (G.single_slab) {
         if ((G.periodic_x && G.Nx <= 2 * G.R) || (G.periodic_y && G.Ny <= 2 * G.R)) {
             g_create_error = "periodic axis shorter than 2*halo_rows+1";
