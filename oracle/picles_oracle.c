@@ -319,10 +319,17 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double sginv2 = (cgp >= 1e-4) ? rc2 : 1e8;
     double ap = (0.5 * dot) * sginv2;
     double ya = ap - 0.85;
-    double H = 1.0 / (1.0 + o_exp((-2.0 * k->p) * ya));
-    double t = o_exp(-20.0 * fabs(ya));
+    /* one reciprocal for H_β and Δ_β: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t(1+eH) r;
+     * t = exp(-20|ya|) is taken as 0 once 5t < 2^-54 (Δ rounds to 1); eH stays finite (argument <= 700) */
+    double harg = (-2.0 * k->p) * ya;
+    double hp = 1.0 + o_exp((harg > 700.0) ? 700.0 : harg);
+    double targ = -20.0 * fabs(ya);
+    double t = (targ <= -40.0) ? 0.0 : o_exp(targ);
     double t1 = 1.0 + t;
-    double D = 1.0 - (5.0 * t) / (t1 * t1);
+    double t12 = t1 * t1;
+    double rHD = 1.0 / (hp * t12);
+    double H = t12 * rHD;
+    double D = 1.0 - ((5.0 * t) * hp) * rHD;
 
     double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0;
     double E2 = 0.0;
@@ -551,7 +558,7 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
     po_rhs(M, idx, unew, uw, vw, k7);
     st->rhs += 6;
 #undef STAGE
-    double at[5];
+    double at[5], sc[5];
     for (int i = 0; i < 5; i++) {
         double ut, m0 = fabs(u0[i]), m1 = fabs(unew[i]);
         double mm = (m0 > m1) ? m0 : m1;
@@ -561,11 +568,23 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
             at[i] = ut / (od->abstol + mm * od->reltol);
         } else {
             double e12 = T->has2 ? PO_FMA(E2, k2[i], E1 * k1[i]) : E1 * k1[i];
-            ut = h * PO_FMA(E7, k7[i], PO_FMA(E6, k6[i], PO_FMA(E5, k5[i], PO_FMA(E4, k4[i], PO_FMA(E3, k3[i], e12)))));
-            at[i] = ut / PO_FMA(mm, od->reltol, od->abstol);
+            at[i] = h * PO_FMA(E7, k7[i], PO_FMA(E6, k6[i], PO_FMA(E5, k5[i], PO_FMA(E4, k4[i], PO_FMA(E3, k3[i], e12)))));
+            sc[i] = PO_FMA(mm, od->reltol, od->abstol);
         }
     }
-    return K ? po_norm5_k(at) : po_norm5_lit(at);
+    if (!K) return po_norm5_lit(at);
+    /* kernel order: returns EEst² = (1/5) Σ (e_i/s_i)² through ONE reciprocal of Π s_i */
+    double p2 = sc[0] * sc[1], p3 = p2 * sc[2], p4 = p3 * sc[3], pp = p4 * sc[4];
+    double q2 = sc[3] * sc[4], q1 = sc[2] * q2, q0 = sc[1] * q1;
+    double n0 = at[0] * q0, n1 = (at[1] * sc[0]) * q1, n2 = (at[2] * p2) * q2;
+    double n3 = (at[3] * p3) * sc[4], n4 = at[4] * p4;
+    double S = n0 * n0;
+    S = PO_FMA(n1, n1, S);
+    S = PO_FMA(n2, n2, S);
+    S = PO_FMA(n3, n3, S);
+    S = PO_FMA(n4, n4, S);
+    double rp = 1.0 / pp;
+    return (S * 0.2) * (rp * rp);
 #undef A21
 #undef A31
 #undef A32
@@ -623,12 +642,13 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
         double rem = DT - tr;
         double h = (dt < rem) ? dt : rem;
         int last = !(dt < rem);
+        /* order 0: EEst; order 1: EEst² (the kernel order never takes the square root) */
         double EEst = po_dp5_try(M, idx, z, k1, t_start + tr, h, unew, k7, st);
         if (!(EEst == EEst)) { EEst = INFINITY; st->status |= PICLES_ST_NONFINITE; }
         int accept = (EEst <= 1.0) || (od->force_dtmin && h <= od->dtmin);
         if (M->order == 1) {
             /* kernel order: PI controller in log space, *qold holds ln(qold) */
-            double le = o_log(EEst);
+            double le = 0.5 * o_log(EEst);
             if (accept) {
                 st->acc++;
                 double qi = o_exp(PO_FMA(beta2, *qold, -(beta1 * le))) * CTRL_GAMMA;

@@ -34,6 +34,7 @@ struct KParams {
     int propagation, input, dissipation, peak_shift, direction, n_is_2;
     /* ODE settings */
     double abstol, reltol, dt0, dtmin;
+    double inv_abstol;       /* 1/abstol: the error scale of a component that is exactly 0 */
     long long maxiters;
     int force_dtmin;
     int solver;              /* 0 DP5, 1 Tsit5 (selects the kernel instantiation) */
@@ -311,16 +312,19 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double sginv2 = (cgp >= 1e-4) ? rc2 : 1e8;
     double ap = (0.5 * dot) * sginv2;
     double ya = ap - 0.85;
-    double H = 1.0 / (1.0 + pm_exp(P.neg2p * ya));
-    /* Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).  For 20|ya| >= 40,
-     * 5t < 2^-54 and the expression rounds to exactly 1.0: skip the exp and the division. */
+    /* H_β = 1/(1+eH), eH = exp(-2p ya);  Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).
+     * One reciprocal serves both: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t (1+eH) r.
+     * For 20|ya| >= 40, 5t < 2^-54 and Δ rounds to exactly 1.0: t is taken as 0 there (no exp),
+     * which also makes H = 1/(1+eH) to the last bit.  eH is kept finite so that 0·eH stays 0. */
+    double hp = 1.0 + pm_exp_finite(P.neg2p * ya);
     double targ = -20.0 * pm_fabs(ya);
-    double D = 1.0;
-    if (!(targ <= -40.0)) {
-        double t = pm_exp(targ);
-        double t1 = 1.0 + t;
-        D = 1.0 - (5.0 * t) / (t1 * t1);
-    }
+    double t = 0.0;
+    if (!(targ <= -40.0)) t = pm_exp_bounded(targ);
+    double t1 = 1.0 + t;
+    double t12 = t1 * t1;
+    double rHD = 1.0 / (hp * t12);
+    double H = t12 * rHD;
+    double D = 1.0 - ((5.0 * t) * hp) * rHD;
     double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, E2 = 0.0;
     if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) E2 = pm_exp(2.0 * lne);
     if (FAST || P.input) It = (P.C_e * H) * (alpha * alpha);
@@ -374,8 +378,12 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
     double r0 = 1.0 / PM_FMA(pm_fabs(u0.lne), P.reltol, P.abstol);
     double r1 = 1.0 / PM_FMA(pm_fabs(u0.cx), P.reltol, P.abstol);
     double r2 = 1.0 / PM_FMA(pm_fabs(u0.cy), P.reltol, P.abstol);
-    double r3 = 1.0 / PM_FMA(pm_fabs(u0.x), P.reltol, P.abstol);
-    double r4 = 1.0 / PM_FMA(pm_fabs(u0.y), P.reltol, P.abstol);
+    /* a freshly remeshed particle sits on its node: x = y = 0, scale = abstol (same bits, no division) */
+    double r3 = P.inv_abstol, r4 = P.inv_abstol;
+    if (u0.x != 0.0 || u0.y != 0.0) {
+        r3 = 1.0 / PM_FMA(pm_fabs(u0.x), P.reltol, P.abstol);
+        r4 = 1.0 / PM_FMA(pm_fabs(u0.y), P.reltol, P.abstol);
+    }
     double d0 = rms5(u0.lne * r0, u0.cx * r1, u0.cy * r2, u0.x * r3, u0.y * r4);
     double d1 = rms5(k1.lne * r0, k1.cx * r1, k1.cy * r2, kx * r3, ky * r4);
     double dt0;
@@ -492,24 +500,41 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         kx = un.cx * ipx; ky = un.cy * ipy;
         ex = PM_FMA(T.e7, kx, ex); ey = PM_FMA(T.e7, ky, ey);
 #define E12(c) (has2 ? PM_FMA(T.e2, k2.c, T.e1 * k1.c) : T.e1 * k1.c)
-#define ERRC(c) ((h * PM_FMA(T.e7, k7.c, PM_FMA(T.e6, k6.c, PM_FMA(T.e5, k5.c, PM_FMA(T.e4, k4.c, PM_FMA(T.e3, k3.c, E12(c))))))) / \
-                 PM_FMA(pm_max(pm_fabs(z.c), pm_fabs(un.c)), P.reltol, P.abstol))
-        double EEst = rms5(ERRC(lne), ERRC(cx), ERRC(cy),
-                           (h * ex) / PM_FMA(pm_max(pm_fabs(z.x), pm_fabs(un.x)), P.reltol, P.abstol),
-                           (h * ey) / PM_FMA(pm_max(pm_fabs(z.y), pm_fabs(un.y)), P.reltol, P.abstol));
+#define ERRN(c) (h * PM_FMA(T.e7, k7.c, PM_FMA(T.e6, k6.c, PM_FMA(T.e5, k5.c, PM_FMA(T.e4, k4.c, PM_FMA(T.e3, k3.c, E12(c)))))))
+#define ERRS(a, b) PM_FMA(pm_max(pm_fabs(a), pm_fabs(b)), P.reltol, P.abstol)
+        /* EEst² = (1/5) Σ (e_i/s_i)² with ONE reciprocal (kernel order): every numerator is
+         * multiplied by the other four scales, the sum is divided by (Π s_i)².  The controller
+         * works on ln EEst = ½ ln EEst², so no square root is taken either. */
+        double EE2;
+        {
+            double s0 = ERRS(z.lne, un.lne), s1 = ERRS(z.cx, un.cx), s2 = ERRS(z.cy, un.cy);
+            double s3 = ERRS(z.x, un.x), s4 = ERRS(z.y, un.y);
+            double p2 = s0 * s1, p3 = p2 * s2, p4 = p3 * s3, pp = p4 * s4;
+            double q2 = s3 * s4, q1 = s2 * q2, q0 = s1 * q1;
+            double n0 = ERRN(lne) * q0, n1 = (ERRN(cx) * s0) * q1, n2 = (ERRN(cy) * p2) * q2;
+            double n3 = ((h * ex) * p3) * s4, n4 = (h * ey) * p4;
+            double S = n0 * n0;
+            S = PM_FMA(n1, n1, S);
+            S = PM_FMA(n2, n2, S);
+            S = PM_FMA(n3, n3, S);
+            S = PM_FMA(n4, n4, S);
+            double rp = 1.0 / pp;
+            EE2 = (S * 0.2) * (rp * rp);
+        }
 #undef ST3
 #undef ST4
 #undef ST5
 #undef ST6
 #undef ST7
-#undef ERRC
+#undef ERRN
+#undef ERRS
 #undef S72
 #undef E12
-        if (!(EEst == EEst)) { EEst = pm_inf(); st.status |= 128 /*PICLES_ST_NONFINITE*/; }
+        if (!(EE2 == EE2)) { EE2 = pm_inf(); st.status |= 128 /*PICLES_ST_NONFINITE*/; }
         /* PI controller in log space (kernel order): 1/q = γ·qold^β2 / EEst^β1, clamped to
          * [qmin, qmax]; lq = ln(qold) is the carried controller memory. One log + one exp per step. */
-        double le = pm_log(EEst);
-        bool accept = (EEst <= 1.0) || (P.force_dtmin && h <= P.dtmin);
+        double le = 0.5 * pm_log(EE2);
+        bool accept = (EE2 <= 1.0) || (P.force_dtmin && h <= P.dtmin);
         if (accept) {
             st.acc++;
             double qi = pm_exp(PM_FMA(beta2, lq, -(beta1 * le))) * PI_GAMMA;

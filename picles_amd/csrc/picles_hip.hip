@@ -946,6 +946,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.propagation = p->propagation; P.input = p->input; P.dissipation = p->dissipation;
     P.peak_shift = p->peak_shift; P.direction = p->direction; P.n_is_2 = (P.n == 2.0);
     P.abstol = o->abstol; P.reltol = o->reltol; P.dt0 = o->dt0; P.dtmin = o->dtmin;
+    P.inv_abstol = 1.0 / o->abstol;
     P.maxiters = o->maxiters; P.force_dtmin = o->force_dtmin;
     P.solver = o->solver;
     P.lne_max = o->log_energy_maximum; P.wind_min_sq = o->wind_min_squared;

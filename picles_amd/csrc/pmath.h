@@ -89,13 +89,12 @@ __device__ __forceinline__ void pm_device_init(void) {}   /* host pass of hipcc:
 /* exp(x), branch-free: x = (32 m + j) ln2/32 + r, |r| <= ln2/64; exp(x) = 2^m * 2^(j/32) * P6(r).
  * Out-of-range arguments are clamped and overflow / underflow through the final ldexp;
  * NaN propagates through the polynomial. */
-PM_HD double pm_exp(double x)
+/* core: x already inside [-746, 710] (or NaN) */
+PM_HD double pm_exp_core(double x)
 {
     const double R32 = 46.16624130844683;             /* 32/ln2 */
     const double L_HI = 0.02166084938653512;          /* ln2/32, 32 trailing zero bits */
     const double L_LO = 5.9631716539705866e-12;
-    x = (x > 710.0) ? 710.0 : x;
-    x = (x < -746.0) ? -746.0 : x;
     double k = __builtin_rint(x * R32);
     double r = PM_FMA(-k, L_HI, x);
     r = PM_FMA(-k, L_LO, r);
@@ -111,6 +110,25 @@ PM_HD double pm_exp(double x)
     p = PM_FMA(p, r, 1.0);
     return __builtin_ldexp(PM_EXP_TAB(j) * p, m);
 }
+
+PM_HD double pm_exp(double x)
+{
+    x = (x > 710.0) ? 710.0 : x;
+    x = (x < -746.0) ? -746.0 : x;
+    return pm_exp_core(x);
+}
+
+/* exp(min(x, 700)): never overflows (callers that multiply the result by a possible zero) */
+PM_HD double pm_exp_finite(double x)
+{
+    x = (x > 700.0) ? 700.0 : x;
+    x = (x < -746.0) ? -746.0 : x;
+    return pm_exp_core(x);
+}
+
+/* exp(x) for callers that guarantee |x| <= 700 or x NaN: same bits as pm_exp, no clamps
+ * (a NaN reaches the table through a masked index and propagates through the polynomial) */
+PM_HD double pm_exp_bounded(double x) { return pm_exp_core(x); }
 
 /* log(x), branch-free main path (fdlibm style: x = 2^k (1+f), s = f/(2+f),
  * log(1+f) = f - hfsq + s (hfsq + R(s^2))), special cases selected at the end */
