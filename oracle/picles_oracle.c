@@ -312,12 +312,12 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double kp = (0.25 * G0) * (minv * minv);
     double a = (0.5 * U) * rc;
     double alpha = (a > 500.0) ? 500.0 : a;
-    double gx = cx * k->inv_rg, gy = cy * k->inv_rg;
-    double dot = PO_FMA(u, gx, v * gy);
-    double crs = u * gy - v * gx;
+    /* dot / cross products on the raw c̄; the 1/r_g factors ride in the constants */
+    double dotc = PO_FMA(u, cx, v * cy);
+    double crsc = u * cy - v * cx;
     double rc2 = rc * rc;
     double sginv2 = (cgp >= 1e-4) ? rc2 : 1e8;
-    double ap = (0.5 * dot) * sginv2;
+    double ap = ((0.5 * k->inv_rg) * dotc) * sginv2;
     double ya = ap - 0.85;
     /* one reciprocal for H_β and Δ_β: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t(1+eH) r;
      * t = exp(-20|ya|) is taken as 0 once 5t < 2^-54 (Δ rounds to 1); eH stays finite (argument <= 700) */
@@ -331,35 +331,36 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double H = t12 * rHD;
     double D = 1.0 - ((5.0 * t) * hp) * rHD;
 
-    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0;
-    double E2 = 0.0;
+    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, Ek = 0.0;
+    double aH = (alpha * alpha) * H;
     int n_is_2 = (k->n == 2.0);
-    if ((ph->dissipation && n_is_2) || ph->peak_shift) E2 = o_exp(2.0 * lne);
-    if (ph->input) It = (ph->C_e * H) * (alpha * alpha);
+    if ((ph->dissipation && n_is_2) || ph->peak_shift) {
+        double k2 = kp * kp;
+        Ek = o_exp(2.0 * lne) * (k2 * k2);
+    }
+    if (ph->input) It = ph->C_e * aH;
     if (ph->dissipation) {
-        double ke = kp * k->inv_eT;
         if (n_is_2) {
-            double ke2 = ke * ke;
-            Dt = E2 * (ke2 * ke2);
+            double ie2 = k->inv_eT * k->inv_eT;
+            Dt = Ek * (ie2 * ie2);
         } else {
+            double ke = kp * k->inv_eT;
             Dt = o_exp(k->n * lne) * o_pow(ke, 2.0 * k->n);
         }
     }
-    if (ph->peak_shift) {
-        double k2 = kp * kp;
-        Scg = ((ph->C_alpha * D) * (k2 * k2)) * E2;
-    }
+    if (ph->peak_shift) Scg = (ph->C_alpha * D) * Ek;
     if (ph->direction) {
         double s2;
         if (U == 0.0 || cgp == 0.0)
             s2 = 0.0;
         else
-            s2 = ((2.0 * crs) * dot) * (rc2 * (1.0 / U2));
+            s2 = (((2.0 * (k->inv_rg * k->inv_rg)) * crsc) * dotc) * (rc2 * (1.0 / U2));
         {   /* opt-in dead band (picles_phys.dir_deadband) */
             double db2 = ph->dir_deadband * ph->dir_deadband;
+            double crs = crsc * k->inv_rg;
             if (db2 > 0.0 && crs * crs <= db2 * (U2 * (cgp * cgp))) s2 = 0.0;
         }
-        Sd = (((alpha * alpha) * ph->C_phi) * H) * s2;
+        Sd = (ph->C_phi * aH) * s2;
     }
     double wrS = (wp * ph->r_g) * Scg;
     if (M->pc) Sd = Sd + cx * M->pc[idx];   /* great-circle term rides on the direction term */

@@ -29,6 +29,7 @@ struct KParams {
     /* physics */
     double r_g, inv_rg, C_alpha, C_phi, C_e;
     double p, n, neg2p, inv_eT;
+    double inv_eT4, half_inv_rg, two_inv_rg2;   /* (1/e_T)⁴, 1/(2 r_g), 2/r_g² */
     double inv_dx, inv_dy;
     double deadband2;       /* dir_deadband² (0 = off) */
     int propagation, input, dissipation, peak_shift, direction, n_is_2;
@@ -305,12 +306,13 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double kp = (0.25 * PK_G0) * (minv * minv);
     double a = W.halfU * rc;
     double alpha = (a > 500.0) ? 500.0 : a;
-    double gx = cx * P.inv_rg, gy = cy * P.inv_rg;
-    double dot = PM_FMA(u, gx, v * gy);
-    double crs = u * gy - v * gx;
+    /* dot and cross products on the raw c̄ (the 1/r_g factors ride in the constants below);
+     * the cross product is two rounded products and one subtraction: exactly 0 for c̄x = c̄y, u = v */
+    double dotc = PM_FMA(u, cx, v * cy);
+    double crsc = u * cy - v * cx;
     double rc2 = rc * rc;
     double sginv2 = (cgp >= 1e-4) ? rc2 : 1e8;
-    double ap = (0.5 * dot) * sginv2;
+    double ap = (P.half_inv_rg * dotc) * sginv2;
     double ya = ap - 0.85;
     /* H_β = 1/(1+eH), eH = exp(-2p ya);  Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).
      * One reciprocal serves both: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t (1+eH) r.
@@ -325,31 +327,34 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double rHD = 1.0 / (hp * t12);
     double H = t12 * rHD;
     double D = 1.0 - ((5.0 * t) * hp) * rHD;
-    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, E2 = 0.0;
-    if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) E2 = pm_exp(2.0 * lne);
-    if (FAST || P.input) It = (P.C_e * H) * (alpha * alpha);
+    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, Ek = 0.0;
+    const double aH = (alpha * alpha) * H;
+    if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) {
+        double k2 = kp * kp;
+        Ek = pm_exp(2.0 * lne) * (k2 * k2);      /* e² k_p⁴: shared by the dissipation and the peak shift */
+    }
+    if (FAST || P.input) It = P.C_e * aH;
     if (FAST || P.dissipation) {
-        double ke = kp * P.inv_eT;
         if (FAST || P.n_is_2) {
-            double ke2 = ke * ke;
-            Dt = E2 * (ke2 * ke2);
+            Dt = Ek * P.inv_eT4;
         } else {
+            double ke = kp * P.inv_eT;
             Dt = pm_exp(P.n * lne) * pm_pow(ke, 2.0 * P.n);
         }
     }
-    if (FAST || P.peak_shift) {
-        double k2 = kp * kp;
-        Scg = ((P.C_alpha * D) * (k2 * k2)) * E2;
-    }
+    if (FAST || P.peak_shift) Scg = (P.C_alpha * D) * Ek;
     if (FAST || P.direction) {
         double s2;
         if (W.U == 0.0 || cgp == 0.0)
             s2 = 0.0;
         else
-            s2 = ((2.0 * crs) * dot) * (rc2 * W.invU2);
+            s2 = ((P.two_inv_rg2 * crsc) * dotc) * (rc2 * W.invU2);
         /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned */
-        if (!FAST && P.deadband2 > 0.0 && crs * crs <= P.deadband2 * (W.U2 * (cgp * cgp))) s2 = 0.0;   /* FAST kernels are only selected with the dead band off */
-        Sd = (((alpha * alpha) * P.C_phi) * H) * s2;
+        if (!FAST && P.deadband2 > 0.0) {   /* FAST kernels are only selected with the dead band off */
+            double crs = crsc * P.inv_rg;
+            if (crs * crs <= P.deadband2 * (W.U2 * (cgp * cgp))) s2 = 0.0;
+        }
+        Sd = (P.C_phi * aH) * s2;
     }
     double wrS = (wp * P.r_g) * Scg;
     if (METRIC) Sd = Sd + cx * pc;   /* great-circle term S_sphere = PC(c̄x) = c̄x·coef rides on S_dir */

@@ -403,11 +403,13 @@ __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &
 __device__ __forceinline__ void pull_candidate(const double *__restrict__ rec, unsigned int off, unsigned int pl, int di, int dj,
                                                int grp, bool ok, double &s0, double &s1, double &s2)
 {
-    double code = rec[off + 5u * pl];
-    int cg, bx, by;
-    rec_decode(code, cg, bx, by);
-    int ax = -di - bx, ay = -dj - by;
-    if (ok && code != 0.0 && cg == grp && ax >= 0 && ax <= 1 && ay >= 0 && ay <= 1) {
+    /* the source feeds this node iff its group matches and its cell offset is (-di - ax, -dj - ay) with
+     * ax, ay in {0, 1}: in code space that is code - code(grp, -di - 1, -dj - 1) in {0, 4, 16384, 16388}
+     * (bit 2 clear = upper x node, bit 14 clear = upper y node); an empty record (code 0) gives a negative
+     * difference */
+    const int d = (int)rec[off + 5u * pl] - (grp + 4 * (REC_BIAS - 1 - di) + 4 * 4096 * (REC_BIAS - 1 - dj));
+    if (ok && (d & ~(4 | 16384)) == 0) {
+        const bool ax = !(d & 4), ay = !(d & 16384);
         double wxh = rec[off + 3u * pl], wyh = rec[off + 4u * pl];
         double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
         s0 += w * rec[off];
@@ -941,6 +943,9 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.neg2p = -2.0 * P.p;
     double e_T = std::sqrt(p->c_e * pm_pow(p->c_alpha, -P.p / q) / pm_pow(p->gamma * p->c_beta * p->c_D, 1.0 / P.n));
     P.inv_eT = 1.0 / e_T;
+    P.inv_eT4 = (P.inv_eT * P.inv_eT) * (P.inv_eT * P.inv_eT);
+    P.half_inv_rg = 0.5 * P.inv_rg;
+    P.two_inv_rg2 = 2.0 * (P.inv_rg * P.inv_rg);
     P.inv_dx = 1.0 / g->dx; P.inv_dy = 1.0 / g->dy;
     P.deadband2 = p->dir_deadband * p->dir_deadband;
     P.propagation = p->propagation; P.input = p->input; P.dissipation = p->dissipation;
