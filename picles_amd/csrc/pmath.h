@@ -45,7 +45,7 @@ PM_HD double pm_nan(void) { return pm_from_bits(0x7ff8000000000000ULL); }
 PM_HD int pm_isnan(double x) { return x != x; }
 PM_HD int pm_isinf(double x) { return (pm_bits(x) & 0x7fffffffffffffffULL) == 0x7ff0000000000000ULL; }
 PM_HD int pm_isfinite(double x) { return (pm_bits(x) & 0x7ff0000000000000ULL) != 0x7ff0000000000000ULL; }
-PM_HD double pm_fabs(double x) { return pm_from_bits(pm_bits(x) & 0x7fffffffffffffffULL); }
+PM_HD double pm_fabs(double x) { return __builtin_fabs(x); }   /* folds into a source modifier on the device */
 PM_HD double pm_max(double a, double b) { return (a > b) ? a : b; }   /* not NaN-propagating on b */
 PM_HD double pm_min(double a, double b) { return (a < b) ? a : b; }
 
@@ -111,18 +111,35 @@ PM_HD double pm_exp_core(double x)
     return __builtin_ldexp(PM_EXP_TAB(j) * p, m);
 }
 
+/* The clamps are the identity for |x| <= 700.  On the device they sit behind a wave-uniform test
+ * (one compare instead of two compare+select pairs when every lane of the wave is in range — the
+ * normal case); the result is the same bit pattern either way. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PM_WAVE_ALL(c) __all(c)
+#define PM_RARE_PATH() asm volatile("")   /* keeps the rare path a real branch (no if-conversion into selects) */
+#else
+#define PM_WAVE_ALL(c) (c)
+#define PM_RARE_PATH() ((void)0)
+#endif
+
 PM_HD double pm_exp(double x)
 {
-    x = (x > 710.0) ? 710.0 : x;
-    x = (x < -746.0) ? -746.0 : x;
+    if (!PM_WAVE_ALL(pm_fabs(x) <= 700.0)) {
+        PM_RARE_PATH();
+        x = (x > 710.0) ? 710.0 : x;
+        x = (x < -746.0) ? -746.0 : x;
+    }
     return pm_exp_core(x);
 }
 
 /* exp(min(x, 700)): never overflows (callers that multiply the result by a possible zero) */
 PM_HD double pm_exp_finite(double x)
 {
-    x = (x > 700.0) ? 700.0 : x;
-    x = (x < -746.0) ? -746.0 : x;
+    if (!PM_WAVE_ALL(pm_fabs(x) <= 700.0)) {
+        PM_RARE_PATH();
+        x = (x > 700.0) ? 700.0 : x;
+        x = (x < -746.0) ? -746.0 : x;
+    }
     return pm_exp_core(x);
 }
 

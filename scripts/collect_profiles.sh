@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round measurement suite, run on the GPU box from the repo root:
+#   gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh r1'
+# then, back in the build container:  python scripts/make_profiles.py r1
+# Each rocprofv3 pass is its own process; the --pmc passes carry no trace domains.
+set -o pipefail
+R=${1:-r1}
+O=gpurun_out
+rm -rf $O/${R}_stats $O/${R}_stats_generic $O/${R}_pmc_sq $O/${R}_pmc_fetch $O/${R}_pmc_write
+export TMPDIR=/tmp
+python bench.py --steps 20 --warmup 3 > $O/${R}_bench.json 2> $O/${R}_bench.err &&
+python bench.py --steps 10 --warmup 2 --no-cpu --winds 10,3 > $O/${R}_bench_generic.json 2>> $O/${R}_bench.err &&
+python bench.py --steps 10 --warmup 2 --no-cpu --winds 10,3 --deadband 1e-9 > $O/${R}_bench_generic_deadband.json 2>> $O/${R}_bench.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $O/${R}_stats.log 2>&1 &&
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_stats_generic -- python3 bench.py --steps 10 --warmup 2 --no-cpu --winds 10,3 > $O/${R}_stats_generic.log 2>&1 &&
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${R}_pmc_sq -- python3 bench.py --steps 6 --warmup 2 --no-cpu > $O/${R}_pmc_sq.log 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_pmc_fetch -- python3 bench.py --steps 6 --warmup 2 --no-cpu > $O/${R}_pmc_fetch.log 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_pmc_write -- python3 bench.py --steps 6 --warmup 2 --no-cpu > $O/${R}_pmc_write.log 2>&1 &&
+python scripts/baseline_configs.py 2> /dev/null > $O/${R}_baseline_configs.jsonl &&
+echo "collected $R"
