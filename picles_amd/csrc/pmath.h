@@ -52,63 +52,52 @@ PM_HD double pm_min(double a, double b) { return (a < b) ? a : b; }
 /* 2^k for -1022 <= k <= 1023 */
 PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
 
-/* 2^(j/32), j = 0..31, correctly rounded */
-#define PM_EXP_TAB_INIT                                                                              \
-    {1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577,           \
-     1.1143867425958924, 1.1387886347566916, 1.1637248587775775, 1.189207115002721,                 \
-     1.215247359980469, 1.241857812073484, 1.2690509571917332, 1.2968395546510096,                  \
-     1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951,                 \
-     1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407,                \
-     1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429,                  \
-     1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424,                 \
-     1.8741676341103, 1.9152065613971474, 1.9571441241754002}
+/* 2^(j/512), j = 0..511, correctly rounded, and the reduction constants (generated) */
+#include "pm_exp_tab.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
 /* device: the table lives in LDS (per-lane index => ds_read_b64, no scalar path possible).
  * Every kernel that evaluates pm_exp calls pm_device_init() first. */
-__device__ __constant__ const double PM_EXP_TAB_C[32] = PM_EXP_TAB_INIT;
+__device__ __constant__ const double PM_EXP_TAB_C[PM_EXP_N] = PM_EXP_TAB_INIT;
 __device__ __forceinline__ double *pm_lds_tab(void)
 {
-    __shared__ double tab[32];
+    __shared__ double tab[PM_EXP_N];
     return tab;
 }
 __device__ __forceinline__ void pm_device_init(void)
 {
-    if (threadIdx.x < 32) pm_lds_tab()[threadIdx.x] = PM_EXP_TAB_C[threadIdx.x];
+    for (int i = threadIdx.x; i < PM_EXP_N; i += blockDim.x) pm_lds_tab()[i] = PM_EXP_TAB_C[i];
     __syncthreads();
 }
 #define PM_EXP_TAB(j) (pm_lds_tab()[(j)])
 #else
-static const double PM_EXP_TAB_H[32] = PM_EXP_TAB_INIT;
+static const double PM_EXP_TAB_H[PM_EXP_N] = PM_EXP_TAB_INIT;
 #define PM_EXP_TAB(j) (PM_EXP_TAB_H[(j)])
 #if defined(__HIPCC__)
 __device__ __forceinline__ void pm_device_init(void) {}   /* host pass of hipcc: declaration only */
 #endif
 #endif
 
-/* exp(x), branch-free: x = (32 m + j) ln2/32 + r, |r| <= ln2/64; exp(x) = 2^m * 2^(j/32) * P6(r).
- * Out-of-range arguments are clamped and overflow / underflow through the final ldexp;
- * NaN propagates through the polynomial. */
-/* core: x already inside [-746, 710] (or NaN) */
+/* exp(x): table + short polynomial.  Out-of-range arguments are clamped and overflow / underflow
+ * through the final ldexp; NaN propagates through the polynomial. */
+/* core: x already inside [-746, 710] (or NaN).
+ * x = (512 m + j) ln2/512 + r, |r| <= ln2/1024; exp(x) = 2^m * 2^(j/512) * (1 + r P3(r)); the truncation error
+ * r^5/120 <= 1.2e-18 is far below the rounding of the final product. */
 PM_HD double pm_exp_core(double x)
 {
-    const double R32 = 46.16624130844683;             /* 32/ln2 */
-    const double L_HI = 0.02166084938653512;          /* ln2/32, 32 trailing zero bits */
-    const double L_LO = 5.9631716539705866e-12;
-    double k = __builtin_rint(x * R32);
-    double r = PM_FMA(-k, L_HI, x);
-    r = PM_FMA(-k, L_LO, r);
+    double k = __builtin_rint(x * PM_EXP_RN);
+    double r = PM_FMA(-k, PM_EXP_LHI, x);
+    r = PM_FMA(-k, PM_EXP_LLO, r);
     int ki = (int)k;
-    int j = ki & 31;
-    int m = ki >> 5;
-    double p = 1.388888888888889e-03;                 /* 1/6! */
-    p = PM_FMA(p, r, 8.333333333333333e-03);          /* 1/5! */
-    p = PM_FMA(p, r, 4.1666666666666664e-02);         /* 1/4! */
+    int j = ki & (PM_EXP_N - 1);
+    int m = ki >> PM_EXP_SHIFT;
+    double p = 4.1666666666666664e-02;                /* 1/4! */
     p = PM_FMA(p, r, 1.6666666666666666e-01);         /* 1/3! */
     p = PM_FMA(p, r, 0.5);
     p = PM_FMA(p, r, 1.0);
-    p = PM_FMA(p, r, 1.0);
-    return __builtin_ldexp(PM_EXP_TAB(j) * p, m);
+    double q = p * r;                                 /* expm1(r): small, so T + T q rounds once */
+    double T = PM_EXP_TAB(j);
+    return __builtin_ldexp(PM_FMA(T, q, T), m);
 }
 
 /* The clamps are the identity for |x| <= 700.  On the device they sit behind a wave-uniform test
