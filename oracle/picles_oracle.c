@@ -38,6 +38,7 @@
 #include "../picles_amd/csrc/pmath.h"
 #define o_exp pm_exp
 #define o_log pm_log
+#define o_log_coarse pm_log_coarse
 #define o_pow pm_pow
 #define o_tanh pm_tanh
 #define o_cosh pm_cosh
@@ -47,6 +48,7 @@ static inline double o_exp10(double x) { return pm_exp(x * 2.3025850929940456840
 #else
 #define o_exp exp
 #define o_log log
+#define o_log_coarse log
 #define o_pow pow
 #define o_tanh tanh
 #define o_cosh cosh
@@ -649,7 +651,7 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
         int accept = (EEst <= 1.0) || (od->force_dtmin && h <= od->dtmin);
         if (M->order == 1) {
             /* kernel order: PI controller in log space, *qold holds ln(qold) */
-            double le = 0.5 * o_log(EEst);
+            double le = 0.5 * o_log_coarse(EEst);   /* ~1e-9: the controller needs no more (pmath.h) */
             if (accept) {
                 st->acc++;
                 double qi = o_exp(PO_FMA(beta2, *qold, -(beta1 * le))) * CTRL_GAMMA;
@@ -1300,6 +1302,7 @@ PO_EXPORT void picles_oracle_math(int32_t fn, int64_t n, const double *x, const 
         case 4: out[i] = o_cosh(x[i]); break;
         case 5: out[i] = x[i] / y[i]; break;
         case 6: out[i] = sqrt(x[i]); break;
+        case 7: out[i] = o_log_coarse(x[i]); break;
         default: out[i] = NAN;
         }
     }

@@ -538,7 +538,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         if (!(EE2 == EE2)) { EE2 = pm_inf(); st.status |= 128 /*PICLES_ST_NONFINITE*/; }
         /* PI controller in log space (kernel order): 1/q = γ·qold^β2 / EEst^β1, clamped to
          * [qmin, qmax]; lq = ln(qold) is the carried controller memory. One log + one exp per step. */
-        double le = 0.5 * pm_log(EE2);
+        double le = 0.5 * pm_log_coarse(EE2);
         bool accept = (EE2 <= 1.0) || (P.force_dtmin && h <= P.dtmin);
         if (accept) {
             st.acc++;

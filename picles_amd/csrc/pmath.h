@@ -175,6 +175,24 @@ PM_HD double pm_log(double x)
 }
 
 /* x^y for x > 0 (fetch-relation seeding and e_T only) */
+/* ln(x) to ~1e-9 relative for the step-size controller (x = EEst² >= 0, possibly 0 or +inf):
+ * no special cases — 0 and subnormals come out near -709·…, +inf near +710, which the controller
+ * clamps exactly as it clamps -inf / +inf.  ln m = 2 atanh(s), s = (m-1)/(m+1), m in [√½, √2). */
+PM_HD double pm_log_coarse(double x)
+{
+    uint64_t ux = pm_bits(x);
+    uint32_t hx = (uint32_t)(ux >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    double m = pm_from_bits(((uint64_t)hx << 32) | (ux & 0xffffffffULL));
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = PM_FMA(z, PM_FMA(z, PM_FMA(z, PM_FMA(z, 2.0 / 9.0, 2.0 / 7.0), 2.0 / 5.0), 2.0 / 3.0), 2.0);
+    return PM_FMA((double)k, 6.93147180559945286227e-01, s * p);
+}
+
 PM_HD double pm_pow(double x, double y) { return pm_exp(y * pm_log(x)); }
 
 /* tanh(x) = sign(x) (1-t)/(1+t), t = exp(-2|x|)   (absolute accuracy ~1e-16) */

@@ -17,6 +17,28 @@ def test_exp_log_ulp():
     assert _ulp_err(O.math_fn(1, x), np.log(x)).max() <= 1.0   # numpy log itself is <= 0.5 ulp
 
 
+def test_exp_against_60_digit_decimal():
+    """pm_exp = 2^m · T[j] · (1 + r·P3(r)) with the 512-entry table: below 1 ulp"""
+    import math
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-40, 40, 1500), rng.uniform(-1, 1, 500), rng.uniform(-700, 700, 1000)])
+    y = O.math_fn(0, x)
+    worst = max(abs((Decimal(float(b)) - Decimal(float(a)).exp()) / Decimal(math.ulp(float(b)))) for a, b in zip(x, y))
+    assert worst < 1.0
+
+
+def test_controller_log_is_coarse_but_total():
+    """pm_log_coarse feeds only the step-size controller: ~1e-9 relative, finite for 0 / subnormal / inf"""
+    rng = np.random.default_rng(12)
+    x = np.exp(rng.uniform(-690, 690, 100000))
+    got, ref = O.math_fn(7, x), np.log(x)
+    assert np.max(np.abs(got - ref)) < 2e-9
+    e = O.math_fn(7, np.array([0.0, 5e-324, np.inf, 1.0]))
+    assert e[0] < -700 and e[1] < -700 and e[2] > 700 and np.all(np.isfinite(e)) and abs(e[3]) < 1e-15
+
+
 def test_special_values():
     x = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, 1000.0, -746.0, -1e9, 5e-324, -1.0])
     e = O.math_fn(0, x)
