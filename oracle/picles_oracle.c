@@ -39,6 +39,7 @@
 #define o_exp pm_exp
 #define o_log pm_log
 #define o_log_coarse pm_log_coarse
+#define o_rsqrt pm_rsqrt
 #define o_pow pm_pow
 #define o_tanh pm_tanh
 #define o_cosh pm_cosh
@@ -49,6 +50,7 @@ static inline double o_exp10(double x) { return pm_exp(x * 2.3025850929940456840
 #define o_exp exp
 #define o_log log
 #define o_log_coarse log
+static inline double o_rsqrt(double x) { return 1.0 / sqrt(x); }
 #define o_pow pow
 #define o_tanh tanh
 #define o_cosh cosh
@@ -304,21 +306,21 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     const po_consts *k = &M->k;
     double lne = z[0], cx = z[1], cy = z[2];
     double c2 = PO_FMA(cx, cx, cy * cy);
-    double cbar = sqrt(c2);
     double U2 = PO_FMA(u, u, v * v);
     double U = sqrt(U2);
-    double cgp = cbar * k->inv_rg;
-    double rc = 1.0 / cgp;
-    double minv = (cgp >= 0.1) ? rc : 10.0;
+    /* rc = 1/c_gp = r_g/|c̄| via the shared deterministic rsqrt; the reference's speed floors
+     * (0.1, 1e-4) become ceilings on rc (10, 1e4); a NaN rc (|c̄| = 0) takes the guarded branch */
+    double rc = ph->r_g * o_rsqrt(c2);
+    double minv = (rc <= 10.0) ? rc : 10.0;
     double wp = (0.5 * G0) * minv;
     double kp = (0.25 * G0) * (minv * minv);
     double a = (0.5 * U) * rc;
-    double alpha = (a > 500.0) ? 500.0 : a;
+    double alpha = (a <= 500.0) ? a : 500.0;
     /* dot / cross products on the raw c̄; the 1/r_g factors ride in the constants */
     double dotc = PO_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
     double rc2 = rc * rc;
-    double sginv2 = (cgp >= 1e-4) ? rc2 : 1e8;
+    double sginv2 = (rc <= 1e4) ? rc2 : 1e8;
     double ap = ((0.5 * k->inv_rg) * dotc) * sginv2;
     double ya = ap - 0.85;
     /* one reciprocal for H_β and Δ_β: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t(1+eH) r;
@@ -353,14 +355,13 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     if (ph->peak_shift) Scg = (ph->C_alpha * D) * Ek;
     if (ph->direction) {
         double s2;
-        if (U == 0.0 || cgp == 0.0)
+        if (U == 0.0 || c2 == 0.0)
             s2 = 0.0;
         else
             s2 = (((2.0 * (k->inv_rg * k->inv_rg)) * crsc) * dotc) * (rc2 * (1.0 / U2));
         {   /* opt-in dead band (picles_phys.dir_deadband) */
             double db2 = ph->dir_deadband * ph->dir_deadband;
-            double crs = crsc * k->inv_rg;
-            if (db2 > 0.0 && crs * crs <= db2 * (U2 * (cgp * cgp))) s2 = 0.0;
+            if (db2 > 0.0 && crsc * crsc <= db2 * (U2 * c2)) s2 = 0.0;
         }
         Sd = (ph->C_phi * aH) * s2;
     }
@@ -1303,6 +1304,9 @@ PO_EXPORT void picles_oracle_math(int32_t fn, int64_t n, const double *x, const 
         case 5: out[i] = x[i] / y[i]; break;
         case 6: out[i] = sqrt(x[i]); break;
         case 7: out[i] = o_log_coarse(x[i]); break;
+#ifdef PO_PMATH
+        case 8: out[i] = pm_rsqrt(x[i]); break;
+#endif
         default: out[i] = NAN;
         }
     }

@@ -298,20 +298,21 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
 {
     const double u = W.u, v = W.v;
     double c2 = PM_FMA(cx, cx, cy * cy);
-    double cbar = __builtin_sqrt(c2);
-    double cgp = cbar * P.inv_rg;
-    double rc = 1.0 / cgp;
-    double minv = (cgp >= 0.1) ? rc : 10.0;
+    /* rc = 1/c_gp = r_g/|c̄| through the deterministic reciprocal square root (no sqrt, no division).
+     * Every use of rc passes a guard written so that a NaN (|c̄| = 0, inf or NaN) takes the guarded
+     * branch: the speed floors 0.1 / 1e-4 of the reference become ceilings 10 / 1e4 on rc. */
+    double rc = P.r_g * pm_rsqrt(c2);
+    double minv = (rc <= 10.0) ? rc : 10.0;
     double wp = (0.5 * PK_G0) * minv;
     double kp = (0.25 * PK_G0) * (minv * minv);
     double a = W.halfU * rc;
-    double alpha = (a > 500.0) ? 500.0 : a;
+    double alpha = (a <= 500.0) ? a : 500.0;
     /* dot and cross products on the raw c̄ (the 1/r_g factors ride in the constants below);
      * the cross product is two rounded products and one subtraction: exactly 0 for c̄x = c̄y, u = v */
     double dotc = PM_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
     double rc2 = rc * rc;
-    double sginv2 = (cgp >= 1e-4) ? rc2 : 1e8;
+    double sginv2 = (rc <= 1e4) ? rc2 : 1e8;
     double ap = (P.half_inv_rg * dotc) * sginv2;
     double ya = ap - 0.85;
     /* H_β = 1/(1+eH), eH = exp(-2p ya);  Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).
@@ -345,14 +346,13 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     if (FAST || P.peak_shift) Scg = (P.C_alpha * D) * Ek;
     if (FAST || P.direction) {
         double s2;
-        if (W.U == 0.0 || cgp == 0.0)
+        if (W.U == 0.0 || c2 == 0.0)
             s2 = 0.0;
         else
             s2 = ((P.two_inv_rg2 * crsc) * dotc) * (rc2 * W.invU2);
         /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned */
         if (!FAST && P.deadband2 > 0.0) {   /* FAST kernels are only selected with the dead band off */
-            double crs = crsc * P.inv_rg;
-            if (crs * crs <= P.deadband2 * (W.U2 * (cgp * cgp))) s2 = 0.0;
+            if (crsc * crsc <= P.deadband2 * (W.U2 * c2)) s2 = 0.0;
         }
         Sd = (P.C_phi * aH) * s2;
     }

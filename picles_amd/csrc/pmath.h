@@ -175,6 +175,23 @@ PM_HD double pm_log(double x)
 }
 
 /* x^y for x > 0 (fetch-relation seeding and e_T only) */
+/* 1/sqrt(x) for x > 0 (normal range), ~1 ulp, from +, *, fma and integer ops only — the same bits on
+ * the host and on the device (the hardware v_rsq/v_rcp approximations are not reproducible on a CPU,
+ * and sqrt followed by a division costs twice as many issue slots).  Bit-trick seed (3.4 %), four
+ * Newton steps y += y (1/2 - x/2 y²).  x = 0 gives a huge finite value, never inf. */
+PM_HD double pm_rsqrt(double x)
+{
+    uint32_t hi = 0x5fe6eb50u - ((uint32_t)(pm_bits(x) >> 32) >> 1);
+    double y = pm_from_bits((uint64_t)hi << 32);
+    const double hx = 0.5 * x;
+    double e;
+    e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);
+    e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);
+    e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);
+    e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);
+    return y;
+}
+
 /* ln(x) to ~1e-9 relative for the step-size controller (x = EEst² >= 0, possibly 0 or +inf):
  * no special cases — 0 and subnormals come out near -709·…, +inf near +710, which the controller
  * clamps exactly as it clamps -inf / +inf.  ln m = 2 atanh(s), s = (m-1)/(m+1), m in [√½, √2). */

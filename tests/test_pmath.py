@@ -39,6 +39,20 @@ def test_controller_log_is_coarse_but_total():
     assert e[0] < -700 and e[1] < -700 and e[2] > 700 and np.all(np.isfinite(e)) and abs(e[3]) < 1e-15
 
 
+def test_rsqrt_against_60_digit_decimal():
+    """pm_rsqrt (bit-trick seed + 4 Newton steps, no sqrt / division): below 1 ulp on the normal range"""
+    import math
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    rng = np.random.default_rng(13)
+    x = np.concatenate([np.exp(rng.uniform(-20, 20, 1500)), np.exp(rng.uniform(-600, 600, 1000)), rng.uniform(1, 4, 500)])
+    y = O.math_fn(8, x)
+    worst = max(abs((Decimal(float(b)) - 1 / Decimal(float(a)).sqrt()) / Decimal(math.ulp(float(b)))) for a, b in zip(x, y))
+    assert worst < 1.0
+    z = O.math_fn(8, np.array([0.0, np.inf, np.nan]))
+    assert np.all(np.isnan(z))      # the RHS guards (rc <= 10, a <= 500, rc <= 1e4) route a NaN to the floors
+
+
 def test_special_values():
     x = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, 1000.0, -746.0, -1e9, 5e-324, -1.0])
     e = O.math_fn(0, x)
