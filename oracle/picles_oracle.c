@@ -431,47 +431,91 @@ static inline double po_norm5_k(const double a[5])
 
 /* ode_determine_initdt (OrdinaryDiffEq initdt.jl, out-of-place form), = auto_dt_reset!
  * (mapping_2D.jl:95,103,110).  f0 = f(u0,t) is passed in (it is also the FSAL k1). */
+static double po_initdt_kernel(const po_model *M, int64_t idx, const double u0[5], const double f0[5],
+                               double t, po_pstats *st);
 static double po_initdt(const po_model *M, int64_t idx, const double u0[5], const double f0[5],
                         double t, po_pstats *st)
 {
     const picles_ode *od = &M->od;
+    if (M->order) return po_initdt_kernel(M, idx, u0, f0, t, st);
     double sk[5], a0[5], a1[5];
-    int K = M->order;
     for (int i = 0; i < 5; i++) {
-        sk[i] = K ? PO_FMA(fabs(u0[i]), od->reltol, od->abstol) : od->abstol + fabs(u0[i]) * od->reltol;
-        if (K) {   /* kernel order: one reciprocal per component, the norms multiply by it */
-            sk[i] = 1.0 / sk[i];
-            a0[i] = u0[i] * sk[i];
-            a1[i] = f0[i] * sk[i];
-        } else {
-            a0[i] = u0[i] / sk[i];
-            a1[i] = f0[i] / sk[i];
-        }
+        sk[i] = od->abstol + fabs(u0[i]) * od->reltol;
+        a0[i] = u0[i] / sk[i];
+        a1[i] = f0[i] / sk[i];
     }
-    double d0 = K ? po_norm5_k(a0) : po_norm5_lit(a0);
-    double d1 = K ? po_norm5_k(a1) : po_norm5_lit(a1);
+    double d0 = po_norm5_lit(a0);
+    double d1 = po_norm5_lit(a1);
     double dt0;
     if (d0 < 1e-5 || d1 < 1e-5) dt0 = 1e-6;
-    else dt0 = K ? 0.01 * (d0 / d1) : (d0 / d1) / 100.0;
+    else dt0 = (d0 / d1) / 100.0;
     if (dt0 < 10.0 * 2.220446049250313e-16) return 1e-6;
     double u1[5], f1[5], uw, vw;
-    for (int i = 0; i < 5; i++) u1[i] = K ? PO_FMA(dt0, f0[i], u0[i]) : u0[i] + dt0 * f0[i];
+    for (int i = 0; i < 5; i++) u1[i] = u0[i] + dt0 * f0[i];
     po_wind(M, idx, t + dt0, &uw, &vw);
     po_rhs(M, idx, u1, uw, vw, f1);
     st->rhs++;
-    for (int i = 0; i < 5; i++) a1[i] = K ? (f1[i] - f0[i]) * sk[i] : (f1[i] - f0[i]) / sk[i];
-    double d2 = (K ? po_norm5_k(a1) : po_norm5_lit(a1)) / dt0;
+    for (int i = 0; i < 5; i++) a1[i] = (f1[i] - f0[i]) / sk[i];
+    double d2 = po_norm5_lit(a1) / dt0;
     double m = (d1 > d2) ? d1 : d2;
     double dt1;
     if (m <= 1e-15) {
         double c = dt0 * 1e-3;
         dt1 = (1e-6 > c) ? 1e-6 : c;
     } else {
-        dt1 = K ? o_exp10((2.0 + o_log10(m)) * -0.2) : o_exp10(-(2.0 + o_log10(m)) / 5.0);
+        dt1 = o_exp10(-(2.0 + o_log10(m)) / 5.0);
     }
     double h = 100.0 * dt0;
     if (dt1 < h) h = dt1;
     /* a NaN estimate (non-finite f) must not poison dt: fall back to the smallest step */
+    if (!(h == h)) h = 1e-6;
+    return (od->dtmin > h) ? od->dtmin : h;
+}
+
+/* the same estimate in KERNEL order (physics.h init_dt): one reciprocal for the three state scales,
+ * squared norms, dt0 through the deterministic rsqrt, coarse logarithm for the second-derivative term */
+static inline double po_ms5(const double a[5])
+{
+    double s = a[0] * a[0];
+    for (int i = 1; i < 5; i++) s = PO_FMA(a[i], a[i], s);
+    return s * 0.2;
+}
+static double po_initdt_kernel(const po_model *M, int64_t idx, const double u0[5], const double f0[5],
+                               double t, po_pstats *st)
+{
+    const picles_ode *od = &M->od;
+    double r[5], a0[5], a1[5];
+    double s0 = PO_FMA(fabs(u0[0]), od->reltol, od->abstol);
+    double s1 = PO_FMA(fabs(u0[1]), od->reltol, od->abstol);
+    double s2 = PO_FMA(fabs(u0[2]), od->reltol, od->abstol);
+    double p01 = s0 * s1;
+    double rp = 1.0 / (p01 * s2);
+    r[0] = (s1 * s2) * rp; r[1] = (s0 * s2) * rp; r[2] = p01 * rp;
+    r[3] = 1.0 / PO_FMA(fabs(u0[3]), od->reltol, od->abstol);
+    r[4] = 1.0 / PO_FMA(fabs(u0[4]), od->reltol, od->abstol);
+    for (int i = 0; i < 5; i++) { a0[i] = u0[i] * r[i]; a1[i] = f0[i] * r[i]; }
+    double S0 = po_ms5(a0), S1 = po_ms5(a1);
+    double dt0;
+    if (S0 < 1e-10 || S1 < 1e-10) dt0 = 1e-6;
+    else dt0 = (0.01 * S0) * o_rsqrt(S0 * S1);
+    if (dt0 < 10.0 * 2.220446049250313e-16) return 1e-6;
+    double u1[5], f1[5], uw, vw;
+    for (int i = 0; i < 5; i++) u1[i] = PO_FMA(dt0, f0[i], u0[i]);
+    po_wind(M, idx, t + dt0, &uw, &vw);
+    po_rhs(M, idx, u1, uw, vw, f1);
+    st->rhs++;
+    for (int i = 0; i < 5; i++) a1[i] = (f1[i] - f0[i]) * r[i];
+    double S2 = po_ms5(a1) / (dt0 * dt0);
+    double m2 = (S1 > S2) ? S1 : S2;
+    double dt1;
+    if (!(m2 > 1e-30)) {
+        double c = dt0 * 1e-3;
+        dt1 = (1e-6 > c) ? 1e-6 : c;
+    } else {
+        dt1 = o_exp(PO_FMA(-0.1, o_log_coarse(m2), -0.92103403719761827));
+    }
+    double h = 100.0 * dt0;
+    if (dt1 < h) h = dt1;
     if (!(h == h)) h = 1e-6;
     return (od->dtmin > h) ? od->dtmin : h;
 }

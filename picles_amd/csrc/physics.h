@@ -363,6 +363,17 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     d.cy = -PM_FMA(cx, Sd, cy * wrS);
 }
 
+/* mean square of five numbers (the squared RMS norm) */
+PM_HD double ms5(double a0, double a1, double a2, double a3, double a4)
+{
+    double s = a0 * a0;
+    s = PM_FMA(a1, a1, s);
+    s = PM_FMA(a2, a2, s);
+    s = PM_FMA(a3, a3, s);
+    s = PM_FMA(a4, a4, s);
+    return s * 0.2;
+}
+
 PM_HD double rms5(double a0, double a1, double a2, double a3, double a4)
 {
     double s = a0 * a0;
@@ -379,21 +390,27 @@ template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, const Vec3 &k1, double kx, double ky,
                      double ipx, double ipy, double pc, double t, PStats &st)
 {
-    /* 1/sk once per component (kernel order): the three norms multiply by it */
-    double r0 = 1.0 / PM_FMA(pm_fabs(u0.lne), P.reltol, P.abstol);
-    double r1 = 1.0 / PM_FMA(pm_fabs(u0.cx), P.reltol, P.abstol);
-    double r2 = 1.0 / PM_FMA(pm_fabs(u0.cy), P.reltol, P.abstol);
+    /* kernel order: 1/sk for (lne, c̄x, c̄y) from ONE reciprocal of the product of the three scales;
+     * the RMS norms stay squared (S = d²): dt0 = 0.01 d0/d1 = 0.01 S0 / sqrt(S0 S1) through the
+     * deterministic rsqrt, and the second-derivative estimate works on max(d1², d2²) with the coarse
+     * logarithm (this is a first guess of the step, refined by the controller). */
+    double s0 = PM_FMA(pm_fabs(u0.lne), P.reltol, P.abstol);
+    double s1 = PM_FMA(pm_fabs(u0.cx), P.reltol, P.abstol);
+    double s2 = PM_FMA(pm_fabs(u0.cy), P.reltol, P.abstol);
+    double p01 = s0 * s1;
+    double rp = 1.0 / (p01 * s2);
+    double r0 = (s1 * s2) * rp, r1 = (s0 * s2) * rp, r2 = p01 * rp;
     /* a freshly remeshed particle sits on its node: x = y = 0, scale = abstol (same bits, no division) */
     double r3 = P.inv_abstol, r4 = P.inv_abstol;
     if (u0.x != 0.0 || u0.y != 0.0) {
         r3 = 1.0 / PM_FMA(pm_fabs(u0.x), P.reltol, P.abstol);
         r4 = 1.0 / PM_FMA(pm_fabs(u0.y), P.reltol, P.abstol);
     }
-    double d0 = rms5(u0.lne * r0, u0.cx * r1, u0.cy * r2, u0.x * r3, u0.y * r4);
-    double d1 = rms5(k1.lne * r0, k1.cx * r1, k1.cy * r2, kx * r3, ky * r4);
+    double S0 = ms5(u0.lne * r0, u0.cx * r1, u0.cy * r2, u0.x * r3, u0.y * r4);
+    double S1 = ms5(k1.lne * r0, k1.cx * r1, k1.cy * r2, kx * r3, ky * r4);
     double dt0;
-    if (d0 < 1e-5 || d1 < 1e-5) dt0 = 1e-6;
-    else dt0 = 0.01 * (d0 / d1);
+    if (S0 < 1e-10 || S1 < 1e-10) dt0 = 1e-6;
+    else dt0 = (0.01 * S0) * pm_rsqrt(S0 * S1);
     if (dt0 < 10.0 * 2.220446049250313e-16) return 1e-6;
     double l1 = PM_FMA(dt0, k1.lne, u0.lne), cx1 = PM_FMA(dt0, k1.cx, u0.cx), cy1 = PM_FMA(dt0, k1.cy, u0.cy);
     Vec3 f1;
@@ -401,16 +418,16 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
     rhs3<FAST, METRIC>(P, l1, cx1, cy1, W, f1, pc);
     st.rhs++;
     double f1x = cx1 * ipx, f1y = cy1 * ipy;
-    double d2 = rms5((f1.lne - k1.lne) * r0, (f1.cx - k1.cx) * r1, (f1.cy - k1.cy) * r2,
-                     (f1x - kx) * r3, (f1y - ky) * r4) / dt0;
-    double m = (d1 > d2) ? d1 : d2;
+    double S2 = ms5((f1.lne - k1.lne) * r0, (f1.cx - k1.cx) * r1, (f1.cy - k1.cy) * r2,
+                    (f1x - kx) * r3, (f1y - ky) * r4) / (dt0 * dt0);
+    double m2 = (S1 > S2) ? S1 : S2;
     double dt1;
-    if (m <= 1e-15) {
+    if (!(m2 > 1e-30)) {   /* flat (or non-finite) second-derivative estimate */
         double c = dt0 * 1e-3;
         dt1 = (1e-6 > c) ? 1e-6 : c;
     } else {
-        double l10 = pm_log(m) * 0.43429448190325182765;
-        dt1 = pm_exp(((2.0 + l10) * -0.2) * 2.30258509299404568402);
+        /* 10^(-(2 + log10 m)/5) = exp(-0.2 ln 100 - 0.1 ln m²) */
+        dt1 = pm_exp(PM_FMA(-0.1, pm_log_coarse(m2), -0.92103403719761827));
     }
     double h = 100.0 * dt0;
     if (dt1 < h) h = dt1;
