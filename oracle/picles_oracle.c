@@ -198,25 +198,35 @@ static void po_reseed(const po_model *M, double u, double v, double T, double z[
 }
 
 /* GetParticleEnergyMomentum (core_2D.jl:69-78): m = c̄ e / |c̄|² / 2 */
-static void po_particle_to_charge(const double z[5], double c[3])
+static void po_particle_to_charge(int K, const double z[5], double c[3])
 {
     double e = o_exp(z[0]);
-    double sp = sqrt(z[1] * z[1] + z[2] * z[2]);
     c[0] = e;
+    if (K) {   /* kernel order: |c̄|² without the square root, one division */
+        double q = (0.5 * e) / PO_FMA(z[1], z[1], z[2] * z[2]);
+        c[1] = z[1] * q;
+        c[2] = z[2] * q;
+        return;
+    }
+    double sp = sqrt(z[1] * z[1] + z[2] * z[2]);
     c[1] = z[1] * e / (sp * sp) / 2.0;
     c[2] = z[2] * e / (sp * sp) / 2.0;
 }
-
-/* GetVariablesAtVertex (core_2D.jl:121-128) */
-static void po_charge_to_particle(const double c[3], double z[5])
+static void po_charge_to_particle(int K, const double c[3], double z[5])
 {
     double e = c[0], mx = c[1], my = c[2];
-    double ma = sqrt(mx * mx + my * my);
     z[0] = o_log(e);
-    z[1] = mx * e / (2.0 * (ma * ma));
-    z[2] = my * e / (2.0 * (ma * ma));
     z[3] = 0.0;
     z[4] = 0.0;
+    if (K) {   /* kernel order: |m|² without the square root, one division */
+        double q = e / (2.0 * PO_FMA(mx, mx, my * my));
+        z[1] = mx * q;
+        z[2] = my * q;
+        return;
+    }
+    double ma = sqrt(mx * mx + my * my);
+    z[1] = mx * e / (2.0 * (ma * ma));
+    z[2] = my * e / (2.0 * (ma * ma));
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -576,28 +586,42 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
         double a = h * A21;
         for (int i = 0; i < 5; i++) g[i] = PO_FMA(a, k1[i], u0[i]);
     }
+    /* kernel order, x and y: the tendencies are c̄x/Δx, c̄y/Δy of the stage state, so the tableau sums
+     * Σ a7i c̄_i and Σ e_i c̄_i run on the stage c̄ and meet the projection once, at the end */
+    double sx = A71 * u0[1], sy = A71 * u0[2], ex = E1 * u0[1], ey = E1 * u0[2];
+    const double ipx = M->ph.propagation ? (M->m11 ? M->m11[idx] : M->k.inv_dx) : 0.0;
+    const double ipy = M->ph.propagation ? (M->m22 ? M->m22[idx] : M->k.inv_dy) : 0.0;
+#define XYACC(a7, e) do { sx = PO_FMA(a7, g[1], sx); sy = PO_FMA(a7, g[2], sy); ex = PO_FMA(e, g[1], ex); ey = PO_FMA(e, g[2], ey); } while (0)
     po_wind(M, idx, K ? PO_FMA(C2, h, t) : t + C2 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k2);
+    if (K && T->has2) XYACC(A72, E2);
     STAGE(u0[i] + h * (A31 * k1[i] + A32 * k2[i]),
           PO_FMA(h, PO_FMA(A32, k2[i], A31 * k1[i]), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C3, h, t) : t + C3 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k3);
+    XYACC(A73, E3);
     STAGE(u0[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]),
           PO_FMA(h, PO_FMA(A43, k3[i], PO_FMA(A42, k2[i], A41 * k1[i])), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C4, h, t) : t + C4 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k4);
+    XYACC(A74, E4);
     STAGE(u0[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]),
           PO_FMA(h, PO_FMA(A54, k4[i], PO_FMA(A53, k3[i], PO_FMA(A52, k2[i], A51 * k1[i]))), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C5, h, t) : t + C5 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k5);
+    XYACC(A75, E5);
     STAGE(u0[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]),
           PO_FMA(h, PO_FMA(A65, k5[i], PO_FMA(A64, k4[i], PO_FMA(A63, k3[i], PO_FMA(A62, k2[i], A61 * k1[i])))), u0[i]));
     po_wind(M, idx, t + h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k6);
+    XYACC(A76, E6);
+#undef XYACC
     for (int i = 0; i < 5; i++)
         if (K) {
             double s72 = T->has2 ? PO_FMA(A72, k2[i], A71 * k1[i]) : A71 * k1[i];
             unew[i] = PO_FMA(h, PO_FMA(A76, k6[i], PO_FMA(A75, k5[i], PO_FMA(A74, k4[i], PO_FMA(A73, k3[i], s72)))), u0[i]);
+            if (i == 3) unew[3] = PO_FMA(h, sx * ipx, u0[3]);
+            if (i == 4) unew[4] = PO_FMA(h, sy * ipy, u0[4]);
         } else if (T->has2) {   /* Tsit5 perform_step!: a71 k1 + a72 k2 + ... */
             unew[i] = u0[i] + h * (A71 * k1[i] + A72 * k2[i] + A73 * k3[i] + A74 * k4[i] + A75 * k5[i] + A76 * k6[i]);
         } else {                /* DP5 perform_step!: the zero a72 term does not appear */
@@ -617,6 +641,8 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
         } else {
             double e12 = T->has2 ? PO_FMA(E2, k2[i], E1 * k1[i]) : E1 * k1[i];
             at[i] = h * PO_FMA(E7, k7[i], PO_FMA(E6, k6[i], PO_FMA(E5, k5[i], PO_FMA(E4, k4[i], PO_FMA(E3, k3[i], e12)))));
+            if (i == 3) at[3] = h * (PO_FMA(E7, unew[1], ex) * ipx);
+            if (i == 4) at[4] = h * (PO_FMA(E7, unew[2], ey) * ipy);
             sc[i] = PO_FMA(mm, od->reltol, od->abstol);
         }
     }
@@ -776,7 +802,7 @@ static int po_particle_to_node(po_model *M, int32_t i, int32_t j, const double z
     double xw[2], yw[2], c[3];
     po_index_weight(z[3], i, xi, xw);
     po_index_weight(z[4], j, yi, yw);
-    po_particle_to_charge(z, c);
+    po_particle_to_charge(M->order, z, c);
     static const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 0, 1, 1}; /* construct_loop order */
     for (int k = 0; k < 4; k++) {
         int64_t ii = xi[ox[k]], jj = yi[oy[k]];
@@ -855,7 +881,7 @@ static void po_remesh_particle(po_model *M, int64_t idx, double DT)
     double z[5];
     if (!bnd && (c[0] >= M->md.minimal_state[0]) &&
         (c[1] * c[1] + c[2] * c[2] >= M->md.minimal_state[1])) {           /* A :306-312 */
-        po_charge_to_particle(c, z);
+        po_charge_to_particle(M->order, c, z);
         for (int k = 0; k < 5; k++) M->z[idx + k * M->N] = z[k];
         M->dtn[idx] = -1.0;
         M->on[idx] = 1;
@@ -1027,7 +1053,7 @@ PO_EXPORT int32_t picles_oracle_seed(po_model *M, double t0)
         M->on[n] = (uint8_t)on;
         if (on) {
             double c3[3];
-            po_particle_to_charge(z, c3);
+            po_particle_to_charge(M->order, z, c3);
             M->state[n] = c3[0];
             M->state[n + N] = c3[1];
             M->state[n + 2 * N] = c3[2];
@@ -1166,7 +1192,7 @@ static void po_write_record(po_model *M, int64_t idx, int *reach_out, int *overf
     double flag = 0.0;
     if (M->on[idx] && isfinite(z[3]) && isfinite(z[4])) {
         double c3[3];
-        po_particle_to_charge(z, c3);
+        po_particle_to_charge(M->order, z, c3);
         rr[i] = c3[0]; rr[M->Nx + i] = c3[1]; rr[2 * M->Nx + i] = c3[2]; rr[3 * M->Nx + i] = z[3]; rr[4 * M->Nx + i] = z[4];
         flag = (double)M->grp[idx];
         int64_t xi[2], yi[2];
@@ -1308,8 +1334,8 @@ PO_EXPORT int32_t picles_oracle_time_step_pull(po_model *M, double dt, int32_t f
 /* ---- single-function entry points for unit tests ---------------------------------------- */
 PO_EXPORT void picles_oracle_windsea(double U, double V, double T, double out[3]) { po_windsea(U, V, T, out); }
 PO_EXPORT void picles_oracle_rhs(po_model *M, const double z[5], double u, double v, double dz[5]) { po_rhs(M, 0, z, u, v, dz); }
-PO_EXPORT void picles_oracle_particle_to_charge(const double z[5], double c[3]) { po_particle_to_charge(z, c); }
-PO_EXPORT void picles_oracle_charge_to_particle(const double c[3], double z[5]) { po_charge_to_particle(c, z); }
+PO_EXPORT void picles_oracle_particle_to_charge(const double z[5], double c[3]) { po_particle_to_charge(0, z, c); }
+PO_EXPORT void picles_oracle_charge_to_particle(const double c[3], double z[5]) { po_charge_to_particle(0, c, z); }
 PO_EXPORT void picles_oracle_index_weight(double zp, int32_t i_node, int64_t idx[2], double w[2]) { po_index_weight(zp, i_node, idx, w); }
 /* integrate node idx's wind with an explicit start state over DT; returns rhs/acc/rej in stats[3] */
 PO_EXPORT int32_t picles_oracle_integrate(po_model *M, int64_t idx, double z[5], double *qold, double *dtn,

@@ -257,22 +257,22 @@ PM_HD void reseed(const KParams &P, double u, double v, double T, Vec5 &z)
     z.y = 0.0;
 }
 
-/* GetParticleEnergyMomentum */
+/* GetParticleEnergyMomentum (kernel order: |c̄|² without the square root, one division) */
 PM_HD void particle_to_charge(double lne, double cx, double cy, double &e, double &mx, double &my)
 {
     e = pm_exp(lne);
-    double sp = __builtin_sqrt(cx * cx + cy * cy);
-    mx = cx * e / (sp * sp) / 2.0;
-    my = cy * e / (sp * sp) / 2.0;
+    double q = (0.5 * e) / PM_FMA(cx, cx, cy * cy);
+    mx = cx * q;
+    my = cy * q;
 }
 
-/* GetVariablesAtVertex */
+/* GetVariablesAtVertex (kernel order: |m|² without the square root, one division) */
 PM_HD void charge_to_particle(double e, double mx, double my, Vec5 &z)
 {
-    double ma = __builtin_sqrt(mx * mx + my * my);
+    double q = e / (2.0 * PM_FMA(mx, mx, my * my));
     z.lne = pm_log(e);
-    z.cx = mx * e / (2.0 * (ma * ma));
-    z.cy = my * e / (2.0 * (ma * ma));
+    z.cx = mx * q;
+    z.cy = my * q;
     z.x = 0.0;
     z.y = 0.0;
 }
@@ -468,11 +468,11 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         double h = last ? rem : dt;
         double t = t_start + tr;
         double gl, gx, gy;      /* stage state (lne, c̄x, c̄y) */
-        double kx, ky;          /* stage x,y tendencies */
-        double ax, ay, ex, ey;  /* running Σ a7i k_i and Σ e_i k_i of the x,y components */
-        kx = z.cx * ipx; ky = z.cy * ipy;
-        ax = T.a71 * kx; ay = T.a71 * ky;
-        ex = T.e1 * kx; ey = T.e1 * ky;
+        /* x,y tendencies are c̄x/Δx, c̄y/Δy of the stage state: their tableau sums run on the stage
+         * c̄ itself (Σ a7i c̄_i, Σ e_i c̄_i) and meet the projection 1/Δx, 1/Δy once, at the end */
+        double ax, ay, ex, ey;
+        ax = T.a71 * z.cx; ay = T.a71 * z.cy;
+        ex = T.e1 * z.cx; ey = T.e1 * z.cy;
         {
             double a21h = h * T.a21;
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
@@ -480,47 +480,41 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         wind_stage<STATIC>(P, w, PM_FMA(T.c2, h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k2, pc);
         if (has2) {
-            kx = gx * ipx; ky = gy * ipy;
-            ax = PM_FMA(T.a72, kx, ax); ay = PM_FMA(T.a72, ky, ay);
-            ex = PM_FMA(T.e2, kx, ex); ey = PM_FMA(T.e2, ky, ey);
+            ax = PM_FMA(T.a72, gx, ax); ay = PM_FMA(T.a72, gy, ay);
+            ex = PM_FMA(T.e2, gx, ex); ey = PM_FMA(T.e2, gy, ey);
         }
 #define ST3(c) PM_FMA(h, PM_FMA(T.a32, k2.c, T.a31 * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
         wind_stage<STATIC>(P, w, PM_FMA(T.c3, h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k3, pc);
-        kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(T.a73, kx, ax); ay = PM_FMA(T.a73, ky, ay);
-        ex = PM_FMA(T.e3, kx, ex); ey = PM_FMA(T.e3, ky, ey);
+        ax = PM_FMA(T.a73, gx, ax); ay = PM_FMA(T.a73, gy, ay);
+        ex = PM_FMA(T.e3, gx, ex); ey = PM_FMA(T.e3, gy, ey);
 #define ST4(c) PM_FMA(h, PM_FMA(T.a43, k3.c, PM_FMA(T.a42, k2.c, T.a41 * k1.c)), z.c)
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
         wind_stage<STATIC>(P, w, PM_FMA(T.c4, h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k4, pc);
-        kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(T.a74, kx, ax); ay = PM_FMA(T.a74, ky, ay);
-        ex = PM_FMA(T.e4, kx, ex); ey = PM_FMA(T.e4, ky, ey);
+        ax = PM_FMA(T.a74, gx, ax); ay = PM_FMA(T.a74, gy, ay);
+        ex = PM_FMA(T.e4, gx, ex); ey = PM_FMA(T.e4, gy, ey);
 #define ST5(c) PM_FMA(h, PM_FMA(T.a54, k4.c, PM_FMA(T.a53, k3.c, PM_FMA(T.a52, k2.c, T.a51 * k1.c))), z.c)
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
         wind_stage<STATIC>(P, w, PM_FMA(T.c5, h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k5, pc);
-        kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(T.a75, kx, ax); ay = PM_FMA(T.a75, ky, ay);
-        ex = PM_FMA(T.e5, kx, ex); ey = PM_FMA(T.e5, ky, ey);
+        ax = PM_FMA(T.a75, gx, ax); ay = PM_FMA(T.a75, gy, ay);
+        ex = PM_FMA(T.e5, gx, ex); ey = PM_FMA(T.e5, gy, ey);
 #define ST6(c) PM_FMA(h, PM_FMA(T.a65, k5.c, PM_FMA(T.a64, k4.c, PM_FMA(T.a63, k3.c, PM_FMA(T.a62, k2.c, T.a61 * k1.c)))), z.c)
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k6, pc);
-        kx = gx * ipx; ky = gy * ipy;
-        ax = PM_FMA(T.a76, kx, ax); ay = PM_FMA(T.a76, ky, ay);
-        ex = PM_FMA(T.e6, kx, ex); ey = PM_FMA(T.e6, ky, ey);
+        ax = PM_FMA(T.a76, gx, ax); ay = PM_FMA(T.a76, gy, ay);
+        ex = PM_FMA(T.e6, gx, ex); ey = PM_FMA(T.e6, gy, ey);
 #define S72(c) (has2 ? PM_FMA(T.a72, k2.c, T.a71 * k1.c) : T.a71 * k1.c)
 #define ST7(c) PM_FMA(h, PM_FMA(T.a76, k6.c, PM_FMA(T.a75, k5.c, PM_FMA(T.a74, k4.c, PM_FMA(T.a73, k3.c, S72(c))))), z.c)
         Vec5 un;
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
-        un.x = PM_FMA(h, ax, z.x); un.y = PM_FMA(h, ay, z.y);
+        un.x = PM_FMA(h, ax * ipx, z.x); un.y = PM_FMA(h, ay * ipy, z.y);
         rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, k7, pc);
         st.rhs += 6;
-        kx = un.cx * ipx; ky = un.cy * ipy;
-        ex = PM_FMA(T.e7, kx, ex); ey = PM_FMA(T.e7, ky, ey);
+        ex = PM_FMA(T.e7, un.cx, ex) * ipx; ey = PM_FMA(T.e7, un.cy, ey) * ipy;
 #define E12(c) (has2 ? PM_FMA(T.e2, k2.c, T.e1 * k1.c) : T.e1 * k1.c)
 #define ERRN(c) (h * PM_FMA(T.e7, k7.c, PM_FMA(T.e6, k6.c, PM_FMA(T.e5, k5.c, PM_FMA(T.e4, k4.c, PM_FMA(T.e3, k3.c, E12(c)))))))
 #define ERRS(a, b) PM_FMA(pm_max(pm_fabs(a), pm_fabs(b)), P.reltol, P.abstol)
