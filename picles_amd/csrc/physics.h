@@ -174,6 +174,17 @@ PM_HD void dp_load(DPTab &T, int solver)
 }
 #endif
 
+/* tableau access inside the RK loop: on the device every use is an LDS read (ds_read_b64 with a
+ * wave-uniform address: the LDS port is otherwise idle, and the 26 live constants would cost 52 VGPRs,
+ * the difference between two and three waves per SIMD); on the host a plain struct */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DP_TAB_DECL(solver) const double *const dp_tab_ = dp_lds_tab()
+#define TT(f) (dp_tab_[__builtin_offsetof(DPTab, f) / 8])
+#else
+#define DP_TAB_DECL(solver) DPTab T; dp_load(T, solver)
+#define TT(f) (T.f)
+#endif
+
 struct Vec5 {
     double lne, cx, cy, x, y;
 };
@@ -447,8 +458,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     const double ipy = (FAST || P.propagation) ? (METRIC ? m22 : P.inv_dy) : 0.0;
     Vec3 k1, k2, k3, k4, k5, k6, k7;
     WindD W;
-    DPTab T;
-    dp_load(T, TSIT ? 1 : 0);
+    DP_TAB_DECL(TSIT ? 1 : 0);
     constexpr bool has2 = TSIT;   /* Tsit5: a72, e2 != 0 (compile-time: the DP5 instruction stream is untouched) */
     constexpr double beta1 = TSIT ? PI_BETA1_TSIT : PI_BETA1, beta2 = TSIT ? PI_BETA2_TSIT : PI_BETA2;
     double tr = 0.0;
@@ -471,52 +481,52 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         /* x,y tendencies are c̄x/Δx, c̄y/Δy of the stage state: their tableau sums run on the stage
          * c̄ itself (Σ a7i c̄_i, Σ e_i c̄_i) and meet the projection 1/Δx, 1/Δy once, at the end */
         double ax, ay, ex, ey;
-        ax = T.a71 * z.cx; ay = T.a71 * z.cy;
-        ex = T.e1 * z.cx; ey = T.e1 * z.cy;
+        ax = TT(a71) * z.cx; ay = TT(a71) * z.cy;
+        ex = TT(e1) * z.cx; ey = TT(e1) * z.cy;
         {
-            double a21h = h * T.a21;
+            double a21h = h * TT(a21);
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
         }
-        wind_stage<STATIC>(P, w, PM_FMA(T.c2, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(TT(c2), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k2, pc);
         if (has2) {
-            ax = PM_FMA(T.a72, gx, ax); ay = PM_FMA(T.a72, gy, ay);
-            ex = PM_FMA(T.e2, gx, ex); ey = PM_FMA(T.e2, gy, ey);
+            ax = PM_FMA(TT(a72), gx, ax); ay = PM_FMA(TT(a72), gy, ay);
+            ex = PM_FMA(TT(e2), gx, ex); ey = PM_FMA(TT(e2), gy, ey);
         }
-#define ST3(c) PM_FMA(h, PM_FMA(T.a32, k2.c, T.a31 * k1.c), z.c)
+#define ST3(c) PM_FMA(h, PM_FMA(TT(a32), k2.c, TT(a31) * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(T.c3, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(TT(c3), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k3, pc);
-        ax = PM_FMA(T.a73, gx, ax); ay = PM_FMA(T.a73, gy, ay);
-        ex = PM_FMA(T.e3, gx, ex); ey = PM_FMA(T.e3, gy, ey);
-#define ST4(c) PM_FMA(h, PM_FMA(T.a43, k3.c, PM_FMA(T.a42, k2.c, T.a41 * k1.c)), z.c)
+        ax = PM_FMA(TT(a73), gx, ax); ay = PM_FMA(TT(a73), gy, ay);
+        ex = PM_FMA(TT(e3), gx, ex); ey = PM_FMA(TT(e3), gy, ey);
+#define ST4(c) PM_FMA(h, PM_FMA(TT(a43), k3.c, PM_FMA(TT(a42), k2.c, TT(a41) * k1.c)), z.c)
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(T.c4, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(TT(c4), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k4, pc);
-        ax = PM_FMA(T.a74, gx, ax); ay = PM_FMA(T.a74, gy, ay);
-        ex = PM_FMA(T.e4, gx, ex); ey = PM_FMA(T.e4, gy, ey);
-#define ST5(c) PM_FMA(h, PM_FMA(T.a54, k4.c, PM_FMA(T.a53, k3.c, PM_FMA(T.a52, k2.c, T.a51 * k1.c))), z.c)
+        ax = PM_FMA(TT(a74), gx, ax); ay = PM_FMA(TT(a74), gy, ay);
+        ex = PM_FMA(TT(e4), gx, ex); ey = PM_FMA(TT(e4), gy, ey);
+#define ST5(c) PM_FMA(h, PM_FMA(TT(a54), k4.c, PM_FMA(TT(a53), k3.c, PM_FMA(TT(a52), k2.c, TT(a51) * k1.c))), z.c)
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(T.c5, h, t), W);
+        wind_stage<STATIC>(P, w, PM_FMA(TT(c5), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k5, pc);
-        ax = PM_FMA(T.a75, gx, ax); ay = PM_FMA(T.a75, gy, ay);
-        ex = PM_FMA(T.e5, gx, ex); ey = PM_FMA(T.e5, gy, ey);
-#define ST6(c) PM_FMA(h, PM_FMA(T.a65, k5.c, PM_FMA(T.a64, k4.c, PM_FMA(T.a63, k3.c, PM_FMA(T.a62, k2.c, T.a61 * k1.c)))), z.c)
+        ax = PM_FMA(TT(a75), gx, ax); ay = PM_FMA(TT(a75), gy, ay);
+        ex = PM_FMA(TT(e5), gx, ex); ey = PM_FMA(TT(e5), gy, ey);
+#define ST6(c) PM_FMA(h, PM_FMA(TT(a65), k5.c, PM_FMA(TT(a64), k4.c, PM_FMA(TT(a63), k3.c, PM_FMA(TT(a62), k2.c, TT(a61) * k1.c)))), z.c)
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k6, pc);
-        ax = PM_FMA(T.a76, gx, ax); ay = PM_FMA(T.a76, gy, ay);
-        ex = PM_FMA(T.e6, gx, ex); ey = PM_FMA(T.e6, gy, ey);
-#define S72(c) (has2 ? PM_FMA(T.a72, k2.c, T.a71 * k1.c) : T.a71 * k1.c)
-#define ST7(c) PM_FMA(h, PM_FMA(T.a76, k6.c, PM_FMA(T.a75, k5.c, PM_FMA(T.a74, k4.c, PM_FMA(T.a73, k3.c, S72(c))))), z.c)
+        ax = PM_FMA(TT(a76), gx, ax); ay = PM_FMA(TT(a76), gy, ay);
+        ex = PM_FMA(TT(e6), gx, ex); ey = PM_FMA(TT(e6), gy, ey);
+#define S72(c) (has2 ? PM_FMA(TT(a72), k2.c, TT(a71) * k1.c) : TT(a71) * k1.c)
+#define ST7(c) PM_FMA(h, PM_FMA(TT(a76), k6.c, PM_FMA(TT(a75), k5.c, PM_FMA(TT(a74), k4.c, PM_FMA(TT(a73), k3.c, S72(c))))), z.c)
         Vec5 un;
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax * ipx, z.x); un.y = PM_FMA(h, ay * ipy, z.y);
         rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, k7, pc);
         st.rhs += 6;
-        ex = PM_FMA(T.e7, un.cx, ex) * ipx; ey = PM_FMA(T.e7, un.cy, ey) * ipy;
-#define E12(c) (has2 ? PM_FMA(T.e2, k2.c, T.e1 * k1.c) : T.e1 * k1.c)
-#define ERRN(c) (h * PM_FMA(T.e7, k7.c, PM_FMA(T.e6, k6.c, PM_FMA(T.e5, k5.c, PM_FMA(T.e4, k4.c, PM_FMA(T.e3, k3.c, E12(c)))))))
+        ex = PM_FMA(TT(e7), un.cx, ex) * ipx; ey = PM_FMA(TT(e7), un.cy, ey) * ipy;
+#define E12(c) (has2 ? PM_FMA(TT(e2), k2.c, TT(e1) * k1.c) : TT(e1) * k1.c)
+#define ERRN(c) (h * PM_FMA(TT(e7), k7.c, PM_FMA(TT(e6), k6.c, PM_FMA(TT(e5), k5.c, PM_FMA(TT(e4), k4.c, PM_FMA(TT(e3), k3.c, E12(c)))))))
 #define ERRS(a, b) PM_FMA(pm_max(pm_fabs(a), pm_fabs(b)), P.reltol, P.abstol)
         /* EEst² = (1/5) Σ (e_i/s_i)² with ONE reciprocal (kernel order): every numerator is
          * multiplied by the other four scales, the sum is divided by (Π s_i)².  The controller

@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * k_advance + k_scatter sequence.
  * ---------------------------------------------------------------------------------------- */
 template <bool FAST, bool TSIT>
-__global__ void __launch_bounds__(256) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
+__global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
     dp_device_init(TSIT ? 1 : 0);

@@ -7,7 +7,8 @@ out = root / "profiles"; out.mkdir(exist_ok=True)
 G = root / "gpurun_out"
 
 def pick(d, suffix, must):
-    for f in sorted(glob.glob(str(G / d / "*" / f"*{suffix}")), reverse=True):
+    import os
+    for f in sorted(glob.glob(str(G / d / "*" / f"*{suffix}")), key=os.path.getmtime, reverse=True):   # newest run first
         if must in open(f).read():
             return f
     raise SystemExit(f"no {suffix} with {must} under {d}")
@@ -30,7 +31,7 @@ def agg(d):
 sq, n1 = agg(f"{R}_pmc_sq"); fe, _ = agg(f"{R}_pmc_fetch"); wr, _ = agg(f"{R}_pmc_write")
 seedF, seedW = fe["k_seed"]["FETCH_SIZE"], wr["k_seed"]["WRITE_SIZE"]
 NP = 16777216
-lines = [f"# {R} PMC summary — `bench.py --steps 6 --warmup 2` (4096² periodic box, winds (10,10)), MI355X", "",
+lines = [f"# {R} PMC summary — `bench.py --steps 6 --warmup 2` (4096² periodic box, winds (10,10)), MI355X (scripts/collect_profiles.sh)", "",
          "Separate `rocprofv3 --pmc` passes (SQ set + GRBM_GUI_ACTIVE; FETCH_SIZE; WRITE_SIZE), averages per dispatch.",
          "FETCH_SIZE (KB) is doubled: gfx950 tallies 128-B read requests at 64 B. Calibration on `k_seed`, whose traffic is known",
          f"exactly: reads u0,v0,mask = 17 B/particle = {17*NP/1024:.0f} KB expected, {seedF:.0f} KB reported (ratio {seedF/(17*NP/1024):.4f});",
