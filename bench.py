@@ -61,6 +61,7 @@ def cpu_baseline(args, W, K):
     def run(n):
         cfg = configs.box4096(n=n, U10=args.winds[0], V10=args.winds[1])
         cfg.model["ODEsys"].dir_deadband = getattr(args, "deadband", 0.0)
+        cfg.model["ODEsets"].solver = getattr(args, "solver", "DP5")
         m = SlabModel(cfg.model, 0, 1, backend_factory=fac)
         m.seed()
         for _ in range(W):
@@ -115,6 +116,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--deadband", type=float, default=0.0,
                     help="opt-in picles_phys.dir_deadband (0 = reference-exact RHS; the headline number uses 0)")
+    ap.add_argument("--solver", default="DP5", choices=["DP5", "Tsit5"],
+                    help="ODE solver of the workload (the BASELINE box is quoted on DP5, as benchmarks/bench06 sets it)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")
     args = ap.parse_args()
@@ -145,6 +148,7 @@ def main():
 
     cfg = configs.box4096(n=args.n, U10=args.winds[0], V10=args.winds[1])
     cfg.model["ODEsys"].dir_deadband = args.deadband
+    cfg.model["ODEsets"].solver = args.solver
     model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo)
     model.seed()
     flags = K.STEP_ZERO_FIRST | (K.STEP_ATOMIC if args.atomic else 0)
@@ -210,7 +214,7 @@ def main():
             "config": {
                 "workload": f"box{args.n}: {args.n}x{args.n} TwoDCartesianGridMesh, periodic, 1 particle/cell, "
                             f"constant winds ({args.winds[0]:g},{args.winds[1]:g}), dx=2000 m, dt=600 s, bench06 physics "
-                            "(C_phi=0.04, gamma=0.88, DP5 abstol 1e-4 reltol 1e-3, lne_max=log 27)",
+                            f"(C_phi=0.04, gamma=0.88, {args.solver} abstol 1e-4 reltol 1e-3, lne_max=log 27)",
                 "grid": [args.n, args.n],
                 "particles": int(n_total),
                 "parallelism": f"y-slabs x{world}, forward halo of scatter records ({args.halo} row) over RCCL send/recv",
