@@ -23,7 +23,7 @@ sys.path.insert(0, str(ROOT))
 B_ALG = 64.0          # algorithmic HBM bytes per particle-step (SURVEY §8d / DESIGN.md)
 HBM_PEAK_GBPS = 8000.0
 FP64_PEAK_TFLOPS = 78.6
-FLOP_PER_RHS = 240.0  # executed fp64 flops per RHS evaluation, all-in (2*FMA + MUL + ADD of the RK loop / 6)
+FLOP_PER_RHS = 187.0  # executed fp64 flops per RHS evaluation, all-in: static count of the RK loop of k_step<FAST,DP5> (348 FMA, 375 MUL, 51 ADD per attempt of 6 evaluations)
 
 
 def usable_cores():

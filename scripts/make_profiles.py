@@ -48,11 +48,12 @@ for k in sq:
     lines.append(f"| `{k}` | {n1[k]} | {s['SQ_INSTS_VALU']/waves:.0f} | {busy:.2f} | {rd/1e9:.3f} GB | {wb/1e9:.3f} GB | {(rd+wb)/NP:.0f} |")
     res[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wb, "valu_busy": busy, "valu_insts_per_wave": s["SQ_INSTS_VALU"] / waves}
 dom = [k for k in res if k.startswith("k_step")][0]
+launch_ms = json.loads([l for l in open(out / f"{R}_bench.json") if l.startswith("{")][0])["roofline"]["avg_launch_ms"]
 tot = res[dom]["hbm_read_bytes"] + res[dom]["hbm_write_bytes"]
 lines += ["", f"Reading: the fused `{dom}` (one launch per model step) keeps the fp64 VALU issue port {res[dom]['valu_busy']*100:.0f} % busy — it is",
           f"VALU-issue bound. Its HBM traffic is {tot/1e9:.2f} GB per launch = {tot/NP:.0f} B/particle against the 64 B/particle algorithmic minimum",
           "(records 48 B in + 48 B out, State 24 B out, winds 16 B, controller memory 8+8 B, status 4 B, flags 1 B); at the ≈5 TB/s this",
-          f"chip sustains that is ≈{tot/5e12*1e3:.2f} ms of the ≈4.2 ms launch. Before fusion (k_advance + k_scatter) the step moved 5.5 GB."]
+          f"chip sustains that is ≈{tot/5e12*1e3:.2f} ms of the ≈{launch_ms:.2f} ms launch. Before fusion (k_advance + k_scatter) the step moved 5.5 GB."]
 (out / f"{R}_pmc_summary.md").write_text("\n".join(lines) + "\n")
 json.dump({"config": {"n": 4096, "winds": [10.0, 10.0]}, "dominant": dom, "kernels": res}, open(out / f"{R}_pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines))
