@@ -304,7 +304,7 @@ struct Vec3 {
     double lne, cx, cy;
 };
 
-template <bool FAST, bool METRIC = false>
+template <bool FAST, bool METRIC = false, bool DB = false>
 PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD &W, Vec3 &d, double pc = 0.0)
 {
     const double u = W.u, v = W.v;
@@ -362,7 +362,7 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
         else
             s2 = ((P.two_inv_rg2 * crsc) * dotc) * (rc2 * W.invU2);
         /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned */
-        if (!FAST && P.deadband2 > 0.0) {   /* FAST kernels are only selected with the dead band off */
+        if (DB || (!FAST && P.deadband2 > 0.0)) {   /* DB: the specialised kernel with the dead band compiled in */
             if (crsc * crsc <= P.deadband2 * (W.U2 * c2)) s2 = 0.0;
         }
         Sd = (P.C_phi * aH) * s2;
@@ -397,7 +397,7 @@ PM_HD double rms5(double a0, double a1, double a2, double a3, double a4)
 
 /* ode_determine_initdt (Hairer–Wanner), = auto_dt_reset! after every remesh.
  * f0 = (k1, kx, ky) is the RHS at (u0, t). */
-template <bool FAST, bool STATIC, bool METRIC>
+template <bool FAST, bool STATIC, bool METRIC, bool DB = false>
 PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, const Vec3 &k1, double kx, double ky,
                      double ipx, double ipy, double pc, double t, PStats &st)
 {
@@ -426,7 +426,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
     double l1 = PM_FMA(dt0, k1.lne, u0.lne), cx1 = PM_FMA(dt0, k1.cx, u0.cx), cy1 = PM_FMA(dt0, k1.cy, u0.cy);
     Vec3 f1;
     wind_stage<STATIC>(P, w, t + dt0, W);
-    rhs3<FAST, METRIC>(P, l1, cx1, cy1, W, f1, pc);
+    rhs3<FAST, METRIC, DB>(P, l1, cx1, cy1, W, f1, pc);
     st.rhs++;
     double f1x = cx1 * ipx, f1y = cy1 * ipy;
     double S2 = ms5((f1.lne - k1.lne) * r0, (f1.cx - k1.cx) * r1, (f1.cy - k1.cy) * r2,
@@ -449,7 +449,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
 /* step!(integrator, DT, true): integrate z over [t_start, t_start+DT] with DP5(4).
  * Only the stage derivatives of (lne, c̄x, c̄y) are kept; the x,y rows of the tableau are
  * accumulated as the stages appear (same fma order as the full Butcher sums). */
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false>
 PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, double &dtn,
                          double t_start, double DT, PStats &st, double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
 {
@@ -464,10 +464,10 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     double tr = 0.0;
     if (STATIC) wind_derive(w.u0, w.v0, W);
     else wind_stage<false>(P, w, t_start, W);
-    rhs3<FAST, METRIC>(P, z.lne, z.cx, z.cy, W, k1, pc);
+    rhs3<FAST, METRIC, DB>(P, z.lne, z.cx, z.cy, W, k1, pc);
     st.rhs++;
     double dt = dtn;
-    if (!(dt > 0.0)) dt = init_dt<FAST, STATIC, METRIC>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, pc, t_start, st);
+    if (!(dt > 0.0)) dt = init_dt<FAST, STATIC, METRIC, DB>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, pc, t_start, st);
     long long iter = 0;
     while (tr < DT) {
         iter++;
@@ -488,7 +488,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
         }
         wind_stage<STATIC>(P, w, PM_FMA(TT(c2), h, t), W);
-        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k2, pc);
+        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k2, pc);
         if (has2) {
             ax = PM_FMA(TT(a72), gx, ax); ay = PM_FMA(TT(a72), gy, ay);
             ex = PM_FMA(TT(e2), gx, ex); ey = PM_FMA(TT(e2), gy, ey);
@@ -496,25 +496,25 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #define ST3(c) PM_FMA(h, PM_FMA(TT(a32), k2.c, TT(a31) * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c3), h, t), W);
-        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k3, pc);
+        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k3, pc);
         ax = PM_FMA(TT(a73), gx, ax); ay = PM_FMA(TT(a73), gy, ay);
         ex = PM_FMA(TT(e3), gx, ex); ey = PM_FMA(TT(e3), gy, ey);
 #define ST4(c) PM_FMA(h, PM_FMA(TT(a43), k3.c, PM_FMA(TT(a42), k2.c, TT(a41) * k1.c)), z.c)
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c4), h, t), W);
-        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k4, pc);
+        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k4, pc);
         ax = PM_FMA(TT(a74), gx, ax); ay = PM_FMA(TT(a74), gy, ay);
         ex = PM_FMA(TT(e4), gx, ex); ey = PM_FMA(TT(e4), gy, ey);
 #define ST5(c) PM_FMA(h, PM_FMA(TT(a54), k4.c, PM_FMA(TT(a53), k3.c, PM_FMA(TT(a52), k2.c, TT(a51) * k1.c))), z.c)
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c5), h, t), W);
-        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k5, pc);
+        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k5, pc);
         ax = PM_FMA(TT(a75), gx, ax); ay = PM_FMA(TT(a75), gy, ay);
         ex = PM_FMA(TT(e5), gx, ex); ey = PM_FMA(TT(e5), gy, ey);
 #define ST6(c) PM_FMA(h, PM_FMA(TT(a65), k5.c, PM_FMA(TT(a64), k4.c, PM_FMA(TT(a63), k3.c, PM_FMA(TT(a62), k2.c, TT(a61) * k1.c)))), z.c)
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
-        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k6, pc);
+        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k6, pc);
         ax = PM_FMA(TT(a76), gx, ax); ay = PM_FMA(TT(a76), gy, ay);
         ex = PM_FMA(TT(e6), gx, ex); ey = PM_FMA(TT(e6), gy, ey);
 #define S72(c) (has2 ? PM_FMA(TT(a72), k2.c, TT(a71) * k1.c) : TT(a71) * k1.c)
@@ -522,7 +522,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         Vec5 un;
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax * ipx, z.x); un.y = PM_FMA(h, ay * ipy, z.y);
-        rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, k7, pc);
+        rhs3<FAST, METRIC, DB>(P, un.lne, un.cx, un.cy, W, k7, pc);
         st.rhs += 6;
         ex = PM_FMA(TT(e7), un.cx, ex) * ipx; ey = PM_FMA(TT(e7), un.cy, ey) * ipy;
 #define E12(c) (has2 ? PM_FMA(TT(e2), k2.c, TT(e1) * k1.c) : TT(e1) * k1.c)

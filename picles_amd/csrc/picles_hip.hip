@@ -191,7 +191,7 @@ struct StepStats {
     int reach;
 };
 
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false>
 __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
                                                 double &dtn, double t_start, double DT, StepStats &S,
                                                 double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
@@ -199,7 +199,7 @@ __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w,
     int status = PICLES_ST_STEPPED;
     if (on) {
         S.adv = 1;
-        integrate_dp5<FAST, STATIC, METRIC, TSIT>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc);
+        integrate_dp5<FAST, STATIC, METRIC, TSIT, DB>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc);
         status |= S.st.status;
     } else {
         double u, v;
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * stand-alone k_scatter when somebody looks (flush()).  Results are bit-identical to the
  * k_advance + k_scatter sequence.
  * ---------------------------------------------------------------------------------------- */
-template <bool FAST, bool TSIT>
+template <bool FAST, bool TSIT, bool DB>
 __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, 
             if (br == 1) { qold = PI_LNQOLDINIT; S.reseeds = 1; }
             unsigned int rs = S.reseeds;
             S.reseeds = 0;
-            int status = advance_particle<FAST, true, false, TSIT>(P, w, z, on, qold, dtn, t_start, DT, S);
+            int status = advance_particle<FAST, true, false, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S);
             S.reseeds += rs;
             A.qold[t] = qold;
             A.status[t] = status;
@@ -1330,14 +1330,19 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     if ((rc = step_prologue(c, s))) return rc;
     const KParams &P = c->P;
     Arrays A = arrays_for(c, c->cur ^ 1, c->cur);
-    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
+    /* specialised variant: every physics switch on and n = 2 (all reference scripts); the opt-in dead band is a
+     * compile-time flavour of it */
+    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+    bool db = P.deadband2 > 0.0;
     dim3 grid(nblocks(nt, 256)), block(256);
     timing_begin(c, s, 0);
-#define LAUNCH_STEP(F, T) hipLaunchKernelGGL((k_step<F, T>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
-    if (fast && P.solver) LAUNCH_STEP(true, true);
-    else if (fast) LAUNCH_STEP(true, false);
-    else if (P.solver) LAUNCH_STEP(false, true);
-    else LAUNCH_STEP(false, false);
+#define LAUNCH_STEP(F, T, D) hipLaunchKernelGGL((k_step<F, T, D>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
+    if (fast && db && P.solver) LAUNCH_STEP(true, true, true);
+    else if (fast && db) LAUNCH_STEP(true, false, true);
+    else if (fast && P.solver) LAUNCH_STEP(true, true, false);
+    else if (fast) LAUNCH_STEP(true, false, false);
+    else if (P.solver) LAUNCH_STEP(false, true, false);
+    else LAUNCH_STEP(false, false, false);
 #undef LAUNCH_STEP
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
