@@ -1247,6 +1247,34 @@ PO_EXPORT int32_t picles_oracle_advance_rows(po_model *M, int32_t which)
     return 0;
 }
 
+/* candidate offsets d in [-R, R] of one axis for node coordinate c, in ascending (wrapped) source index —
+ * the reference's sequential visiting order.  Non-periodic: out-of-range sources are dropped.  Periodic with
+ * 2R+1 <= N: the rotation that starts at the smallest wrapped index.  Periodic with 2R+1 > N (a reach that
+ * wraps around the axis): sources 0..N-1 in turn, each with all its aliasing offsets.  Returns the count. */
+static int po_axis_candidates(int c, int N, int R, int periodic, int *d, int *src)
+{
+    int n = 0, W = 2 * R + 1;
+    if (!periodic) {
+        for (int k = -R; k <= R; k++)
+            if (c + k >= 0 && c + k < N) { d[n] = k; src[n++] = c + k; }
+    } else if (W <= N) {
+        int sh = 0;
+        if (c - R < 0) sh = R - c; else if (c + R >= N) sh = N - c + R;
+        for (int q = 0; q < W; q++) {
+            int k = (q + sh) % W - R;
+            d[n] = k; src[n++] = (int)po_wrap(c + k, N);
+        }
+    } else {
+        for (int sidx = 0; sidx < N; sidx++) {
+            int k = sidx - c;
+            int a = k + R, fl = a / N;
+            if (a % N < 0) fl--;
+            for (k -= fl * N; k <= R; k += N) { d[n] = k; src[n++] = sidx; }
+        }
+    }
+    return n;
+}
+
 static void po_pull_node(po_model *M, int i, int jl, int R, int accum, double s[3])
 {
     int j = jl + M->j0, Nx = M->Nx, Ny = M->Ny, W = 2 * R + 1;
@@ -1254,20 +1282,16 @@ static void po_pull_node(po_model *M, int i, int jl, int R, int accum, double s[
     s[0] = accum ? M->state[t] : 0.0;
     s[1] = accum ? M->state[t + M->N] : 0.0;
     s[2] = accum ? M->state[t + 2 * M->N] : 0.0;
-    int shx = 0, shy = 0;
-    if (M->g.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= Nx) shx = Nx - i + R; }
-    if (M->g.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= Ny) shy = Ny - j + R; }
+    int dxs[W], sxs[W], dys[W], sys[W];
+    int nxc = po_axis_candidates(i, Nx, R, M->g.periodic_x, dxs, sxs);
+    int nyc = po_axis_candidates(j, Ny, R, M->g.periodic_y, dys, sys);
     for (int grp = 1; grp <= M->ngroups; grp++)
-        for (int sj = 0; sj < W; sj++) {
-            int dj = (sj + shy) % W - R;
-            int jj = j + dj;
-            if (!M->g.periodic_y && (jj < 0 || jj >= Ny)) continue;
-            int row = M->single_slab ? (int)po_wrap(jj, Ny) + M->R : jl + dj + M->R;
+        for (int a = 0; a < nyc; a++) {
+            int dj = dys[a];
+            int row = M->single_slab ? sys[a] + M->R : jl + dj + M->R;
             const double *rr = po_rec_row(M, row);
-            for (int si = 0; si < W; si++) {
-                int di = (si + shx) % W - R;
-                int ii = i + di;
-                if (ii < 0 || ii >= Nx) { if (!M->g.periodic_x) continue; ii = (int)po_wrap(ii, Nx); }
+            for (int b = 0; b < nxc; b++) {
+                int di = dxs[b], ii = sxs[b];
                 if (rr[5 * Nx + ii] != (double)grp) continue;
                 int64_t xi[2], yi[2];
                 double xw[2], yw[2];

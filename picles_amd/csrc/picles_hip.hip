@@ -396,8 +396,6 @@ __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &
  * Fused: State zero-fill (accum=0), MovieState snapshot + post-remesh zero (movie=1),
  * remesh (REMESH).
  * ---------------------------------------------------------------------------------------- */
-/* sum of the contributions to node (i, j); RT > 0: reach known at compile time (fully unrolled:
- * all candidate codes are loaded before any is inspected), RT == 0: runtime reach R */
 /* one candidate source: record element offset `off` (plane 0 of the source particle), cell offsets
  * (di, dj) of the source relative to the node */
 __device__ __forceinline__ void pull_candidate(const double *__restrict__ rec, unsigned int off, unsigned int pl, int di, int dj,
@@ -415,6 +413,39 @@ __device__ __forceinline__ void pull_candidate(const double *__restrict__ rec, u
         s0 += w * rec[off];
         s1 += w * rec[off + pl];
         s2 += w * rec[off + 2u * pl];
+    }
+}
+
+/* floor(a / b) for b > 0 */
+__device__ __forceinline__ int floor_div(int a, int b) { int q = a / b; return (a % b < 0) ? q - 1 : q; }
+
+/* General form of the pull for a reach that wraps around a periodic axis (2R + 1 > N: tiny grids, huge
+ * steps): several offsets d alias the same source row / column.  Sources are visited in ascending
+ * wrapped index (the reference's sequential order); for each one every aliasing offset is tried (at most
+ * one can match, the cell offset stored in the record decides).  O(N) per axis, only used when needed. */
+__device__ __forceinline__ void pull_node_aliased(const GridP &G, const Arrays &A, int i, int jl, int R,
+                                  double &s0, double &s1, double &s2)
+{
+    const int RO = G.R, Nx = G.Nx, Ny = G.Ny, j = jl + G.j_begin;
+    const double *__restrict__ rec = A.rec;
+    const unsigned int pl = (unsigned int)Nx, rowlen = 6u * pl;
+    const int jlo = G.periodic_y ? 0 : max(0, j - R), jhi = G.periodic_y ? Ny - 1 : min(Ny - 1, j + R);
+    const int ilo = G.periodic_x ? 0 : max(0, i - R), ihi = G.periodic_x ? Nx - 1 : min(Nx - 1, i + R);
+    const bool wrap_y = G.periodic_y && G.single_slab;     /* slabs: a periodic y never aliases (checked at create) */
+    for (int grp = 1; grp <= G.ngroups; grp++) {
+        for (int js = jlo; js <= jhi; js++) {
+            int dj0 = js - j;
+            if (G.periodic_y) dj0 -= floor_div(dj0 + R, Ny) * Ny;          /* smallest alias >= -R */
+            for (int dj = dj0; dj <= R; dj += (G.periodic_y ? Ny : 2 * R + 1)) {
+                const int row = (wrap_y || !G.periodic_y ? js - G.j_begin : jl + dj) + RO;
+                for (int is = ilo; is <= ihi; is++) {
+                    int di0 = is - i;
+                    if (G.periodic_x) di0 -= floor_div(di0 + R, Nx) * Nx;
+                    for (int di = di0; di <= R; di += (G.periodic_x ? Nx : 2 * R + 1))
+                        pull_candidate(rec, (unsigned int)row * rowlen + (unsigned int)is, pl, di, dj, grp, true, s0, s1, s2);
+                }
+            }
+        }
     }
 }
 
@@ -494,6 +525,18 @@ __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i
     }
 }
 
+/* reach dispatch: compile-time reach 1 and 2, runtime reach otherwise; a reach that wraps around a periodic
+ * axis takes the general (aliasing-aware) form */
+__device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i, int jl, int R,
+                                         double &s0, double &s1, double &s2)
+{
+    const int W = 2 * R + 1;
+    if ((G.periodic_x && W > G.Nx) || (G.periodic_y && W > G.Ny)) pull_node_aliased(G, A, i, jl, R, s0, s1, s2);
+    else if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
+    else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
+    else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
+}
+
 template <bool REMESH>
 __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, int accum, int movie,
                                                    double clock, double DT)
@@ -507,9 +550,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
         if (accum) { s0 = A.state[t]; s1 = A.state[t + A.n]; s2 = A.state[t + 2 * A.n]; }
         int R = G.Rp;
         if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
-        if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
-        //R2 else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
-        else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
+        pull_any(G, A, i, jl, R, s0, s1, s2);
         if (movie) {
             A.movie[t] = s0; A.movie[t + A.n] = s1; A.movie[t + 2 * A.n] = s2;
             A.state[t] = 0.0; A.state[t + A.n] = 0.0; A.state[t + 2 * A.n] = 0.0;
@@ -553,9 +594,7 @@ __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, 
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         int R = G.Rp;
         if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
-        if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
-        else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
-        else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
+        pull_any(G, A, i, jl, R, s0, s1, s2);
         A.state[t] = s0; A.state[t + A.n] = s1; A.state[t + 2 * A.n] = s2;
         unsigned char pf = A.pflags[t];
         if (pf & PF_STEPPED) {
@@ -1002,12 +1041,12 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
         delete c;
         return -2;
     }
-    if (G.single_slab) {
-        if ((G.periodic_x && G.Nx <= 2 * G.R) || (G.periodic_y && G.Ny <= 2 * G.R)) {
-            g_create_error = "periodic axis shorter than 2*halo_rows+1";
-            delete c;
-            return -2;
-        }
+    /* a whole-grid context follows any reach (a reach that wraps around a periodic axis takes the general
+     * pull); a slab covers halo_rows of reach, and its periodic y axis must be longer than 2*halo_rows */
+    if (!G.single_slab && ((G.periodic_y && G.Ny <= 2 * G.R) || G.ny_loc < G.R)) {
+        g_create_error = "slab: periodic y axis not longer than 2*halo_rows, or fewer own rows than halo_rows";
+        delete c;
+        return -2;
     }
 
 #define CK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e2); picles_destroy(c); return -10; } } while (0)
@@ -1662,8 +1701,8 @@ PX_EXPORT int32_t picles_set_halo_rows(picles_ctx *c, int32_t r)
     if (!c || r < 1) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->G.single_slab && ((c->G.periodic_x && c->G.Nx <= 2 * r) || (c->G.periodic_y && c->G.Ny <= 2 * r)))
-        return fail(c, -2, "periodic axis shorter than 2*halo_rows+1");
+    if (!c->G.single_slab && ((c->G.periodic_y && c->G.Ny <= 2 * r) || c->G.ny_loc < r))
+        return fail(c, -2, "slab: periodic y axis not longer than 2*halo_rows, or fewer own rows than halo_rows");
     { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     /* keep the records of the own rows: re-pack into the new ghost-row geometry */

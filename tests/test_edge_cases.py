@@ -43,7 +43,7 @@ def test_single_interior_particle(backend):
 
 @pytest.mark.gpu
 def test_tiny_and_ragged_sizes_match_oracle():
-    for n, per in ((3, (False, False)), (5, (True, True)), (7, (True, False)), (65, (False, False)), (129, (True, True))):
+    for n, per in ((2, (True, True)), (3, (True, True)), (3, (False, False)), (5, (True, True)), (7, (True, False)), (65, (False, False)), (129, (True, True))):
         g, o = make_model(_tiny(n, per), "hip"), make_model(_tiny(n, per), ("pmath", 1))
         for m in (g, o):
             initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
@@ -57,11 +57,11 @@ def test_library_refuses_bad_inputs():
     from picles_amd.models import build_structs
     from picles_amd import fetch_relations as FR
     from picles_amd.driver import HipModel
-    cfg = _tiny(2, (True, True))                      # periodic axis shorter than 2*reach+1
+    cfg = _tiny(6, (True, True))                      # a slab whose periodic y axis is not longer than 2*halo_rows
     ms = FR.MinimalState(2, 2, 600.0)
-    g, p, o, m = build_structs(cfg.model["grid"], cfg.model["ODEsys"], cfg.model["ODEsets"], None, ms, True)
-    with pytest.raises(K.PiclesError, match="periodic axis"):
-        HipModel(g, p, o, m, mask=cfg.model["grid"].data.mask)
+    g, p, o, m = build_structs(cfg.model["grid"], cfg.model["ODEsys"], cfg.model["ODEsets"], None, ms, True, j_begin=0, j_end=3)
+    with pytest.raises(K.PiclesError, match="slab: periodic y axis"):
+        HipModel(g, p, o, m, mask=cfg.model["grid"].data.mask, halo_rows=3)
     g, p, o, m = build_structs(_tiny(6).model["grid"], cfg.model["ODEsys"], cfg.model["ODEsets"], None, ms, False)
     g.j_begin, g.j_end = 4, 2
     with pytest.raises(K.PiclesError, match="slab rows"):

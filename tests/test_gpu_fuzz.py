@@ -1,0 +1,95 @@
+"""Randomised parity: seeded random small scenarios — grid shape, spacing, periodicity of either axis, land
+masks, model boundary flag, spatially varying (optionally time-varying, partly calm) winds, solver, time step,
+C_φ, run!/movie stepping — HIP library vs the CPU oracle (pmath backend, kernel order), BITWISE: State after
+every step, the particle list, status flags and the step counters.  Every case is reproducible from its seed."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from picles_amd import fetch_relations as FetchRelations
+from picles_amd.grids import TwoDCartesianGridMesh
+from picles_amd.particle_waves_v5 import ODEParameters, ODESettings, particle_equations
+from picles_amd.simulations import Simulation, initialize_simulation
+from picles_amd.timesteppers import movie_time_step, time_step
+from helpers import make_model, assert_bitwise
+
+pytestmark = pytest.mark.gpu
+ORACLE = ("pmath", 1)
+
+
+def scenario(seed):
+    rng = np.random.default_rng(1000 + seed)
+    nx, ny = int(rng.integers(6, 40)), int(rng.integers(6, 40))
+    dx, dy = float(rng.choice([500.0, 1000.0, 2000.0, 4000.0])), float(rng.choice([500.0, 1000.0, 2000.0, 4000.0]))
+    per = (bool(rng.integers(2)), bool(rng.integers(2)))
+    mask = np.ones((nx, ny), dtype=bool)
+    for _ in range(int(rng.integers(0, 3))):          # rectangular islands
+        i0, j0 = int(rng.integers(0, nx)), int(rng.integers(0, ny))
+        mask[i0:i0 + int(rng.integers(1, 6)), j0:j0 + int(rng.integers(1, 6))] = False
+    if not mask.any():
+        mask[:] = True
+    grid = TwoDCartesianGridMesh(0.0, dx * (nx - 1), nx, 0.0, dy * (ny - 1), ny, mask=mask, periodic_boundary=per)
+    U0, V0 = float(rng.uniform(-15, 15)), float(rng.uniform(-15, 15))
+    A = float(rng.uniform(0, 8))
+    kx, ky = 2 * math.pi / (dx * nx) * int(rng.integers(1, 3)), 2 * math.pi / (dy * ny) * int(rng.integers(1, 3))
+    ph = float(rng.uniform(0, 2 * math.pi))
+    tvar = bool(rng.integers(2))
+    calm = bool(rng.integers(2))
+    om = 2 * math.pi / 7200.0
+
+    def shape(x, y):
+        s = 1.0 + 0 * x
+        if calm:                                       # a calm band: winds below the sqrt(wind_min_squared) gate
+            s = np.where((x > 0.3 * dx * nx) & (x < 0.5 * dx * nx), 1e-3, s)
+        return s
+
+    def u(x, y, t):
+        return (U0 + A * np.sin(kx * x + ph) * np.cos(ky * y) + (2.0 * np.sin(om * t) if tvar else 0.0)) * shape(x, y)
+
+    def v(x, y, t):
+        return (V0 + A * np.cos(kx * x) * np.sin(ky * y + ph) + (1.5 * np.cos(om * t) if tvar else 0.0)) * shape(x, y)
+
+    DT = float(rng.choice([600.0, 900.0, 1800.0]))
+    ODEpars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
+    psys = particle_equations(u, v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
+    pars = dict(ODEpars)
+    if rng.integers(2):
+        pars["C_φ"] = Const_ID.c_β                   # the strong direction relaxation of T04 / bench06
+    ws = FetchRelations.MinimalWindsea(10.0, 10.0, DT)
+    sets = ODESettings(Parameters=pars, log_energy_minimum=ws["lne"], log_energy_maximum=math.log(27),
+                       saving_step=DT, timestep=DT, total_time=6 * 86400.0, dt=1e-3, dtmin=1e-4, force_dtmin=True,
+                       solver=str(rng.choice(["DP5", "Tsit5"])))
+    model = dict(grid=grid, winds=SimpleNamespace(u=u, v=v), ODEsys=psys, ODEsets=sets,
+                 periodic_boundary=bool(rng.integers(2)), minimal_particle=FetchRelations.MinimalParticle(10.0, 10.0, DT),
+                 movie=True, winds_static=not tvar)
+    return SimpleNamespace(model=model, Δt=DT, n_steps=int(rng.integers(3, 7)), mode=str(rng.choice(["run", "movie"])),
+                           desc=f"{nx}x{ny} per={per} tvar={tvar} calm={calm} {sets.solver} DT={DT}")
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scenario_bitwise(seed):
+    g, o = make_model(scenario(seed), "hip"), make_model(scenario(seed), ORACLE)
+    cfg = scenario(seed)
+    for m in (g, o):
+        initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    assert_bitwise(g.State, o.State, f"seed {seed} ({cfg.desc}): State after init")
+    for k in range(cfg.n_steps):
+        for m in (g, o):
+            if cfg.mode == "run":
+                time_step(m, cfg.Δt, zero_first=True)
+            else:
+                movie_time_step(m, cfg.Δt)
+        a, b = (g.State, o.State) if cfg.mode == "run" else (g.MovieState, o.MovieState)
+        assert_bitwise(a, b, f"seed {seed} ({cfg.desc}): step {k}")
+    zg, ong, _, stg = g.backend.get_particles()
+    zo, ono, _, sto = o.backend.get_particles()
+    assert_bitwise(ong, ono, "on")
+    assert_bitwise(stg, sto, "status")
+    stepped = (sto & 1) == 1
+    for c in range(5):
+        assert_bitwise(zg[..., c][stepped], zo[..., c][stepped], f"seed {seed}: z[{c}]")
+    cg, co = g.backend.get_counters(), o.backend.get_counters()
+    for key in ("particles_advanced", "rhs_evals", "steps_accepted", "steps_rejected", "reseeds", "max_reach"):
+        assert cg[key] == co[key], (seed, key, cg[key], co[key])

@@ -322,3 +322,23 @@ def test_run_without_observers_uses_one_call_and_matches_stepwise():
     run(sb, cash_store=True)                           # step by step with snapshots
     assert a.clock.time == b.clock.time == 13 * 600.0 and a.clock.iteration == 13
     assert np.array_equal(a.State, sb.store.store[-1])
+
+
+@pytest.mark.parametrize("nx,ny,per", [(7, 6, (True, True)), (26, 6, (False, True)), (5, 19, (True, False)), (3, 3, (True, True))])
+def test_reach_wrapping_around_a_periodic_axis_bitwise(nx, ny, per):
+    """2R+1 > N on a periodic axis: aliasing offsets; the kernels take the general pull (found by test_gpu_fuzz.py)"""
+    def cfg():
+        c = configs.bench06_box(n=8, dx=500.0, U10=9.0, V10=-4.0)
+        c.Δt = 1800.0
+        c.model["grid"] = TwoDCartesianGridMesh(0.0, 500.0 * (nx - 1), nx, 0.0, 500.0 * (ny - 1), ny, periodic_boundary=per)
+        return c
+    g, o = _pair(cfg)
+    for m in (g, o):
+        _init(m, 1800.0)
+    for k in range(6):
+        for m in (g, o):
+            time_step(m, 1800.0, zero_first=True)
+        assert_bitwise(g.State, o.State, f"State step {k}")
+    R = g.backend.get_counters()["max_reach"]
+    assert (per[0] and 2 * R + 1 > nx) or (per[1] and 2 * R + 1 > ny), R
+    _same_particles(g, o)

@@ -64,3 +64,22 @@ def test_pull_with_large_reach_and_land_mask():
     for k, (a, b) in enumerate(zip(A, B)):
         assert_bitwise(b, a, f"step {k}")
     assert np.all(A[-1][9:13, 10:15, 0][1:-1, 1:-1] >= 0)
+
+
+@pytest.mark.parametrize("nx,ny,per", [(7, 6, (True, True)), (26, 6, (False, True)), (5, 19, (True, False)), (3, 3, (True, True))])
+def test_pull_when_the_reach_wraps_around_a_periodic_axis(nx, ny, per):
+    """2R+1 > N on a periodic axis (tiny grid, 30-minute steps at 500 m spacing): several offsets alias the same
+    source; the pull must still visit sources in the sequential order of the push (found by tests/test_gpu_fuzz.py)."""
+    from picles_amd.grids import TwoDCartesianGridMesh
+
+    def cfg():
+        c = configs.bench06_box(n=8, dx=500.0, U10=9.0, V10=-4.0)
+        c.Δt = 1800.0
+        c.model["grid"] = TwoDCartesianGridMesh(0.0, 500.0 * (nx - 1), nx, 0.0, 500.0 * (ny - 1), ny, periodic_boundary=per)
+        return c
+    ma, A = _run(cfg(), False, 5)
+    mb, B = _run(cfg(), True, 5)
+    R = ma.backend.get_counters()["max_reach"]
+    assert (per[0] and 2 * R + 1 > nx) or (per[1] and 2 * R + 1 > ny), R
+    for k, (a, b) in enumerate(zip(A, B)):
+        assert_bitwise(b, a, f"step {k}")
