@@ -135,7 +135,7 @@ class SlabModel:
     `cfg_model` are the WaveGrowth2D keyword arguments (picles_amd.configs)."""
 
     def __init__(self, cfg_model: dict, rank: int, world: int, device: int = 0, halo_rows: int = 1,
-                 backend_factory=None, use_streams=True):
+                 backend_factory=None, use_streams=True, exchange=None):
         from . import fetch_relations as FetchRelations
         grid, ODEsys, ODEsets = cfg_model["grid"], cfg_model["ODEsys"], cfg_model["ODEsets"]
         self.grid, self.winds = grid, cfg_model["winds"]
@@ -163,8 +163,12 @@ class SlabModel:
         self._wind_window = None
         self.n_stepped = self._count_stepped()
         self.use_streams = use_streams and world > 1 and backend_factory is None
-        self.ex = (HaloExchange(self.backend, rank, world, self.periodic_y, host_blocks=backend_factory is not None)
-                   if world > 1 else None)
+        if exchange is not None:          # caller-supplied exchange object (start() / finish(works)), e.g. several slabs in one process
+            self.ex = exchange
+            self.use_streams = False
+        else:
+            self.ex = (HaloExchange(self.backend, rank, world, self.periodic_y, host_blocks=backend_factory is not None)
+                       if world > 1 else None)
         if self.use_streams:
             import torch
             self.s_edge = torch.cuda.Stream()

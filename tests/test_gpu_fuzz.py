@@ -53,7 +53,18 @@ def scenario(seed):
 
     DT = float(rng.choice([600.0, 900.0, 1800.0]))
     ODEpars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
-    psys = particle_equations(u, v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
+    sw = dict(propagation=True, input=True, dissipation=True, peak_shift=True, direction=True)
+    q = Const_ID.q
+    flavour = int(rng.integers(4))                    # 0, 1: the specialised kernels; 2: switches; 3: n != 2 or dead band
+    if flavour == 2:
+        for key in sw:
+            sw[key] = bool(rng.random() < 0.7)
+    psys = particle_equations(u, v, γ=Const_ID.γ, q=q, IDConstants=Const_ID, **sw)
+    if flavour == 3:
+        if rng.integers(2):
+            psys = particle_equations(u, v, γ=Const_ID.γ, q=-0.3, IDConstants=Const_ID)      # n = 2q/(p+4q) != 2: pow path
+        else:
+            psys.dir_deadband = 1e-9
     pars = dict(ODEpars)
     if rng.integers(2):
         pars["C_φ"] = Const_ID.c_β                   # the strong direction relaxation of T04 / bench06
@@ -65,10 +76,10 @@ def scenario(seed):
                  periodic_boundary=bool(rng.integers(2)), minimal_particle=FetchRelations.MinimalParticle(10.0, 10.0, DT),
                  movie=True, winds_static=not tvar)
     return SimpleNamespace(model=model, Δt=DT, n_steps=int(rng.integers(3, 7)), mode=str(rng.choice(["run", "movie"])),
-                           desc=f"{nx}x{ny} per={per} tvar={tvar} calm={calm} {sets.solver} DT={DT}")
+                           desc=f"{nx}x{ny} per={per} tvar={tvar} calm={calm} {sets.solver} DT={DT} flavour={flavour} {sw}")
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(64))
 def test_random_scenario_bitwise(seed):
     g, o = make_model(scenario(seed), "hip"), make_model(scenario(seed), ORACLE)
     cfg = scenario(seed)
