@@ -24,7 +24,7 @@ if world > 1:
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
 cfg = configs.box4096(n_steps=50)
-model = SlabModel(cfg.model, rank, world, device=local, halo_rows=2)   # the scatter reach of this box grows to 2 cells after ~45 steps
+model = SlabModel(cfg.model, rank, world, device=local, halo_rows=2, auto_halo_every=8)   # the reach of this box grows to 2 cells after ~45 steps; ghost rows follow it
 model.seed()
 t0 = time.perf_counter()
 for k in range(cfg.n_steps):

@@ -135,7 +135,7 @@ class SlabModel:
     `cfg_model` are the WaveGrowth2D keyword arguments (picles_amd.configs)."""
 
     def __init__(self, cfg_model: dict, rank: int, world: int, device: int = 0, halo_rows: int = 1,
-                 backend_factory=None, use_streams=True, exchange=None):
+                 backend_factory=None, use_streams=True, exchange=None, auto_halo_every: int = 0):
         from . import fetch_relations as FetchRelations
         grid, ODEsys, ODEsets = cfg_model["grid"], cfg_model["ODEsys"], cfg_model["ODEsets"]
         self.grid, self.winds = grid, cfg_model["winds"]
@@ -160,6 +160,10 @@ class SlabModel:
         self.static = bool(cfg_model.get("winds_static", False))
         self.timestep = ODEsets.timestep
         self.clock = 0.0
+        # > 0: every that many steps all ranks compare the largest scatter reach seen so far with halo_rows and
+        # add a ghost row (collectively) as soon as the reach has used them all — before a particle can overshoot
+        self.auto_halo_every = int(auto_halo_every)
+        self._steps_done = 0
         self._wind_window = None
         self.n_stepped = self._count_stepped()
         self.use_streams = use_streams and world > 1 and backend_factory is None
@@ -242,6 +246,27 @@ class SlabModel:
             self.ex.finish(works)
             b.scatter_remesh()
         self.clock += dt
+        self._steps_done += 1
+        if self.auto_halo_every > 0 and self.world > 1 and self._steps_done % self.auto_halo_every == 0:
+            self.grow_halo_if_needed()
+
+    def grow_halo_if_needed(self):
+        """collective: if any rank's scatter reach has reached halo_rows, every rank adds one ghost row.
+        The reach of a developing sea grows by a fraction of a cell per model step, so checking every few
+        steps stays ahead of it; an actual overshoot is still counted in `halo_overflow`."""
+        import torch
+        import torch.distributed as dist
+        self.sync()
+        reach = torch.tensor([float(self.backend.get_counters()["max_reach"])], dtype=torch.float64,
+                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(reach, op=dist.ReduceOp.MAX)
+        have = self.backend.halo_rows
+        if int(reach[0]) >= have:
+            self.backend.set_halo_rows(have + 1)
+            if hasattr(self.ex, "rebind"):
+                self.ex.rebind()
+            return have + 1
+        return have
 
     def sync(self):
         self.backend.sync()

@@ -26,7 +26,8 @@ def _cfg(name):
             "nonperiodic_generic": lambda: configs.T04_2D_reg_test(U10=10.0, V10=3.0, periodic=False, n=45, L=176e3),
             "calm": lambda: configs.growing_decaying_winds(n=48),
             "periodic_model_ring": lambda: configs.T04_2D_reg_test(U10=-10.0, V10=10.0, periodic=True, n=45, L=176e3),
-            "sphere": lambda: configs.sphere_aqua(nx=46, ny=45, n_steps=4)}[name]()
+            "sphere": lambda: configs.sphere_aqua(nx=46, ny=45, n_steps=4),
+            "growing_reach": lambda: configs.bench06_box(n=64, dx=1400.0)}[name]()
 
 
 def _worker(rank, world, port, name, n_steps, halo, outdir):
@@ -35,7 +36,8 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     cfg = _cfg(name)
-    model = SlabModel(cfg.model, rank, world, device=0, halo_rows=halo)
+    auto = 2 if name == "growing_reach" else 0
+    model = SlabModel(cfg.model, rank, world, device=0, halo_rows=halo, auto_halo_every=auto)
     model.seed()
     for _ in range(n_steps):
         model.time_step(cfg.Δt)
@@ -44,6 +46,8 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
     if rank == 0:
         np.save(os.path.join(outdir, "state.npy"), S)
     assert ov == 0
+    if auto:
+        assert model.backend.halo_rows > halo
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,6 +66,22 @@ def test_gpu_slabs_equal_single_context(tmp_path, name, world, halo):
         one.time_step(cfg.Δt)
     ref = one.get_state()
     assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
+
+
+def test_gpu_halo_rows_grow_with_the_reach(tmp_path):
+    """auto_halo_every on the HIP library (fused slab steps, ghost rows re-packed mid-run): the reach passes from 1
+    to 2 cells at step 11 of this box; the run starts with one ghost row and must never overflow"""
+    from picles_amd.parallel import SlabModel
+    n_steps = 14
+    mp.spawn(_worker, args=(2, _free_port(), "growing_reach", n_steps, 1, str(tmp_path)), nprocs=2, join=True)
+    S = np.load(tmp_path / "state.npy")
+    cfg = _cfg("growing_reach")
+    one = SlabModel(cfg.model, 0, 1, device=0)
+    one.seed()
+    for _ in range(n_steps):
+        one.time_step(cfg.Δt)
+    assert one.backend.get_counters()["max_reach"] == 2
+    assert np.array_equal(S, one.get_state())
 
 
 def test_halo_blocks_are_zero_copy_torch_views():

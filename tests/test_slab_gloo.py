@@ -30,6 +30,8 @@ def _cfg(name):
         return configs.T04_2D_reg_test(U10=-10.0, V10=10.0, periodic=True, n=25, L=96e3)
     if name == "calm":
         return configs.growing_decaying_winds(n=24)
+    if name == "growing_reach":           # 1.4 km spacing: the developing sea's scatter reach passes from 1 to 2 cells at step 11
+        return configs.bench06_box(n=24, dx=1400.0)
     raise KeyError(name)
 
 
@@ -43,7 +45,8 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
         return O.OracleModel(g, p, o, m, kind="pmath", order=1, threads=1, mask=mask, halo_rows=halo_rows)
 
     cfg = _cfg(name)
-    model = SlabModel(cfg.model, rank, world, halo_rows=halo, backend_factory=fac)
+    auto = 1 if name == "growing_reach" else 0
+    model = SlabModel(cfg.model, rank, world, halo_rows=halo, backend_factory=fac, auto_halo_every=auto)
     model.seed()
     for _ in range(n_steps):
         model.time_step(cfg.Δt)
@@ -52,6 +55,8 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
     if rank == 0:
         np.save(os.path.join(outdir, "state.npy"), S)
     assert ov == 0
+    if auto:
+        assert model.backend.halo_rows > halo >= 1     # the ghost rows grew with the reach, ahead of it
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,6 +85,15 @@ def test_slabs_equal_single_domain(tmp_path, name, world, halo):
     S = np.load(tmp_path / "state.npy")
     ref = _single(name, n_steps)
     assert S.shape == ref.shape
+    assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
+
+
+def test_halo_rows_grow_with_the_reach(tmp_path):
+    """auto_halo_every: a run that starts with one ghost row and whose reach passes 2 cells never overflows"""
+    n_steps = 14
+    mp.spawn(_worker, args=(2, _free_port(), "growing_reach", n_steps, 1, str(tmp_path)), nprocs=2, join=True)
+    S = np.load(tmp_path / "state.npy")
+    ref = _single("growing_reach", n_steps)
     assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
 
 
