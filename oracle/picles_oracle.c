@@ -321,16 +321,16 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     /* rc = 1/c_gp = r_g/|c̄| via the shared deterministic rsqrt; the reference's speed floors
      * (0.1, 1e-4) become ceilings on rc (10, 1e4); a NaN rc (|c̄| = 0) takes the guarded branch */
     double rc = ph->r_g * o_rsqrt(c2);
-    double minv = (rc <= 10.0) ? rc : 10.0;
+    double minv = fmin(rc, 10.0);            /* IEEE minNum: a NaN rc gives the floor */
     double wp = (0.5 * G0) * minv;
     double kp = (0.25 * G0) * (minv * minv);
     double a = (0.5 * U) * rc;
-    double alpha = (a <= 500.0) ? a : 500.0;
+    double alpha = fmin(a, 500.0);
     /* dot / cross products on the raw c̄; the 1/r_g factors ride in the constants */
     double dotc = PO_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
     double rc2 = rc * rc;
-    double sginv2 = (rc <= 1e4) ? rc2 : 1e8;
+    double sginv2 = fmin(rc2, 1e8);
     double ap = ((0.5 * k->inv_rg) * dotc) * sginv2;
     double ya = ap - 0.85;
     /* one reciprocal for H_β and Δ_β: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t(1+eH) r;
@@ -643,7 +643,7 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
             at[i] = h * PO_FMA(E7, k7[i], PO_FMA(E6, k6[i], PO_FMA(E5, k5[i], PO_FMA(E4, k4[i], PO_FMA(E3, k3[i], e12)))));
             if (i == 3) at[3] = h * (PO_FMA(E7, unew[1], ex) * ipx);
             if (i == 4) at[4] = h * (PO_FMA(E7, unew[2], ey) * ipy);
-            sc[i] = PO_FMA(mm, od->reltol, od->abstol);
+            sc[i] = PO_FMA(fmax(m0, m1), od->reltol, od->abstol);
         }
     }
     if (!K) return po_norm5_lit(at);
@@ -726,9 +726,8 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
             if (accept) {
                 st->acc++;
                 double qi = o_exp(PO_FMA(beta2, *qold, -(beta1 * le))) * CTRL_GAMMA;
-                qi = (qi > CTRL_QMAX) ? CTRL_QMAX : qi;
-                qi = (qi < CTRL_QMIN) ? CTRL_QMIN : qi;
-                *qold = (le > CTRL_LNQOLDINIT) ? le : CTRL_LNQOLDINIT;
+                qi = fmax(fmin(qi, CTRL_QMAX), CTRL_QMIN);
+                *qold = fmax(le, CTRL_LNQOLDINIT);
                 dt = h * qi;
                 for (int i = 0; i < 5; i++) { z[i] = unew[i]; k1[i] = k7[i]; }
                 tr = last ? DT : tr + h;
@@ -736,7 +735,7 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
             } else {
                 st->rej++;
                 double r = CTRL_GAMMA * o_exp(-(beta1 * le));
-                r = (r < CTRL_QMIN) ? CTRL_QMIN : r;
+                r = fmax(r, CTRL_QMIN);
                 dt = h * r;
                 if (!od->force_dtmin && h <= od->dtmin) { st->status |= PICLES_ST_DTMIN; break; }
             }

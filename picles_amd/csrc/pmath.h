@@ -48,6 +48,10 @@ PM_HD int pm_isfinite(double x) { return (pm_bits(x) & 0x7ff0000000000000ULL) !=
 PM_HD double pm_fabs(double x) { return __builtin_fabs(x); }   /* folds into a source modifier on the device */
 PM_HD double pm_max(double a, double b) { return (a > b) ? a : b; }   /* not NaN-propagating on b */
 PM_HD double pm_min(double a, double b) { return (a < b) ? a : b; }
+/* IEEE minNum / maxNum: a NaN operand yields the other one.  One v_min_f64 / v_max_f64 on the device
+ * (a compare + two selects otherwise); fmin / fmax on the host: identical results, NaNs included. */
+PM_HD double pm_fmin(double a, double b) { return __builtin_fmin(a, b); }
+PM_HD double pm_fmax(double a, double b) { return __builtin_fmax(a, b); }
 
 /* 2^k for -1022 <= k <= 1023 */
 PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
