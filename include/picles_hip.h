@@ -180,7 +180,8 @@ int32_t picles_store_push(picles_ctx *ctx);
 int32_t picles_store_pop(picles_ctx *ctx, double *state, double *time);
 int32_t picles_store_pending(const picles_ctx *ctx);
 
-/* particles (own rows; z is 5 planes: lne, c̄x, c̄y, x, y). Any pointer may be NULL. */
+/* particles (own rows; z is 5 planes: lne, c̄x, c̄y, x, y). Any pointer may be NULL.
+ * The state vector of a switched-off particle (on == 0) is dead storage: its content is unspecified. */
 int32_t picles_get_particles(picles_ctx *ctx, double *z, uint8_t *on, uint8_t *boundary,
                              int32_t *status);
 int32_t picles_set_particles(picles_ctx *ctx, const double *z, const uint8_t *on);

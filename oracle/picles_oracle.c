@@ -317,19 +317,17 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double lne = z[0], cx = z[1], cy = z[2];
     double c2 = PO_FMA(cx, cx, cy * cy);
     double U2 = PO_FMA(u, u, v * v);
-    double U = sqrt(U2);
     /* rc = 1/c_gp = r_g/|c̄| via the shared deterministic rsqrt; the reference's speed floors
      * (0.1, 1e-4) become ceilings on rc (10, 1e4); a NaN rc (|c̄| = 0) takes the guarded branch */
     double rc = ph->r_g * o_rsqrt(c2);
     double minv = fmin(rc, 10.0);            /* IEEE minNum: a NaN rc gives the floor */
     double wp = (0.5 * G0) * minv;
     double kp = (0.25 * G0) * (minv * minv);
-    double a = (0.5 * U) * rc;
-    double alpha = fmin(a, 500.0);
+    double rc2 = rc * rc;
+    double alpha2 = fmin((0.25 * U2) * rc2, 250000.0);   /* α² = min(U/(2 c_gp), 500)²: the wind speed itself is never formed */
     /* dot / cross products on the raw c̄; the 1/r_g factors ride in the constants */
     double dotc = PO_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
-    double rc2 = rc * rc;
     double sginv2 = fmin(rc2, 1e8);
     double ap = ((0.5 * k->inv_rg) * dotc) * sginv2;
     double ya = ap - 0.85;
@@ -346,7 +344,7 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double D = 1.0 - ((5.0 * t) * hp) * rHD;
 
     double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, Ek = 0.0;
-    double aH = (alpha * alpha) * H;
+    double aH = alpha2 * H;
     int n_is_2 = (k->n == 2.0);
     if ((ph->dissipation && n_is_2) || ph->peak_shift) {
         double k2 = kp * kp;
@@ -365,7 +363,7 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     if (ph->peak_shift) Scg = (ph->C_alpha * D) * Ek;
     if (ph->direction) {
         double s2;
-        if (U == 0.0 || c2 == 0.0)
+        if (U2 == 0.0 || c2 == 0.0)
             s2 = 0.0;
         else
             s2 = (((2.0 * (k->inv_rg * k->inv_rg)) * crsc) * dotc) * (rc2 * (1.0 / U2));

@@ -201,16 +201,15 @@ struct PStats {
 /* node wind at absolute time t plus the quantities every RHS evaluation derives from it.
  * For time-constant winds they are computed once per particle-step (same arithmetic, hoisted). */
 struct WindD {
-    double u, v, U2, U, invU2, halfU;
+    double u, v, U2, invU2, qU2;   /* U² = u²+v², 1/U², U²/4 — the wind speed itself is never needed (α enters as α²) */
 };
 PM_HD void wind_derive(double u, double v, WindD &d)
 {
     d.u = u;
     d.v = v;
     d.U2 = PM_FMA(u, u, v * v);
-    d.U = __builtin_sqrt(d.U2);
     d.invU2 = 1.0 / d.U2;
-    d.halfU = 0.5 * d.U;
+    d.qU2 = 0.25 * d.U2;
 }
 PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double &v)
 {
@@ -316,13 +315,12 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double minv = pm_fmin(rc, 10.0);
     double wp = (0.5 * PK_G0) * minv;
     double kp = (0.25 * PK_G0) * (minv * minv);
-    double a = W.halfU * rc;
-    double alpha = pm_fmin(a, 500.0);
+    double rc2 = rc * rc;
+    double alpha2 = pm_fmin(W.qU2 * rc2, 250000.0);     /* α² = min(U/(2 c_gp), 500)² */
     /* dot and cross products on the raw c̄ (the 1/r_g factors ride in the constants below);
      * the cross product is two rounded products and one subtraction: exactly 0 for c̄x = c̄y, u = v */
     double dotc = PM_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
-    double rc2 = rc * rc;
     double sginv2 = pm_fmin(rc2, 1e8);      /* = (rc <= 1e4) ? rc² : 1e8, NaN -> 1e8 */
     double ap = (P.half_inv_rg * dotc) * sginv2;
     double ya = ap - 0.85;
@@ -340,7 +338,7 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double H = t12 * rHD;
     double D = 1.0 - ((5.0 * t) * hp) * rHD;
     double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, Ek = 0.0;
-    const double aH = (alpha * alpha) * H;
+    const double aH = alpha2 * H;
     if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) {
         double k2 = kp * kp;
         Ek = pm_exp(2.0 * lne) * (k2 * k2);      /* e² k_p⁴: shared by the dissipation and the peak shift */
@@ -357,7 +355,7 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     if (FAST || P.peak_shift) Scg = (P.C_alpha * D) * Ek;
     if (FAST || P.direction) {
         double s2;
-        if (W.U == 0.0 || c2 == 0.0)
+        if (W.U2 == 0.0 || c2 == 0.0)
             s2 = 0.0;
         else
             s2 = ((P.two_inv_rg2 * crsc) * dotc) * (rc2 * W.invU2);

@@ -69,6 +69,7 @@ struct Arrays {
     unsigned char *on, *pflags;
     int *status;
     double *u0, *v0, *u1, *v1;
+    double *uP, *vP;         /* level-0 winds of the previous step's window (fused steps under time-varying winds) */
     double *m11, *m22, *pc;  /* per-node projection diag and great-circle coefficient (NULL: Cartesian) */
     double *rec;             /* records the scatter reads  (latest completed advance) */
     double *rec_out;         /* records the advance writes (the other buffer of the pair) */
@@ -370,6 +371,23 @@ __device__ __forceinline__ int remesh_regs(const KParams &P, const Wind &w, unsi
     return 2;
 }
 
+/* the same decision with the node wind behind pointers: it is read only by the (rare) branches that need it */
+__device__ __forceinline__ int remesh_regs_lazy(const KParams &P, unsigned char pf, double e, double mx, double my,
+                                                double DT, Vec5 &z, const double *pu, const double *pv)
+{
+    bool bnd = (pf & PF_BOUNDARY) != 0;
+    if (!bnd && (e >= P.min_e) && (mx * mx + my * my >= P.min_m2)) {
+        charge_to_particle(e, mx, my, z);
+        return 0;
+    }
+    double u = *pu, v = *pv;
+    if (u * u + v * v >= P.wind_min_sq) {
+        reseed(P, u, v, DT, z);
+        return 1;
+    }
+    return 2;
+}
+
 __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &A, long long t, unsigned char pf,
                                                 double e, double mx, double my, double clock, double DT,
                                                 unsigned int &reseeds)
@@ -580,7 +598,9 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * stand-alone k_scatter when somebody looks (flush()).  Results are bit-identical to the
  * k_advance + k_scatter sequence.
  * ---------------------------------------------------------------------------------------- */
-template <bool FAST, bool TSIT, bool DB>
+/* STATIC = false: winds linear in time over the step window (u0,v0 -> u1,v1); the remesh of the previous step
+ * needs the wind at ITS start-of-step clock = level 0 of the previous window, kept in (uP, vP) */
+template <bool FAST, bool TSIT, bool DB, bool STATIC>
 __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
@@ -601,12 +621,12 @@ __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, 
             Wind w = load_wind(P, A, t);
             Vec5 z = {0.0, 0.0, 0.0, 0.0, 0.0};
             double qold = A.qold[t], dtn = -1.0;
-            int br = remesh_regs(P, w, pf, s0, s1, s2, t_prev, DT_prev, z);
+            int br = remesh_regs_lazy(P, pf, s0, s1, s2, DT_prev, z, STATIC ? &A.u0[t] : &A.uP[t], STATIC ? &A.v0[t] : &A.vP[t]);
             int on = (br <= 1);
             if (br == 1) { qold = PI_LNQOLDINIT; S.reseeds = 1; }
             unsigned int rs = S.reseeds;
             S.reseeds = 0;
-            int status = advance_particle<FAST, true, false, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S);
+            int status = advance_particle<FAST, STATIC, false, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S);
             S.reseeds += rs;
             A.qold[t] = qold;
             A.status[t] = status;
@@ -856,6 +876,7 @@ struct picles_ctx {
     double *d_wgu = nullptr, *d_wgv = nullptr;
     double wind_t1 = 0.0;          /* time level currently held in (u1, v1) */
     bool wind_t1_valid = false;
+    bool ext_streams = false;      /* a caller-provided stream has been used: order across streams with device syncs */
     /* generic scatter scratch */
     int *d_count = nullptr, *d_start = nullptr, *d_cursor = nullptr;
     void *d_scan_tmp = nullptr;
@@ -1088,6 +1109,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     Arrays &A = c->A;
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
+    if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
     hipFree(A.cnt); hipFree(c->d_mask);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
     for (int k = 0; k < 2; k++) { hipFree(c->rec_buf[k]); hipFree(c->mr_buf[k]); }
@@ -1319,6 +1341,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (stream) c->ext_streams = true;
     int r0, n0, r1, n1;
     int rc = select_rows(c, which, r0, n0, r1, n1);
     if (rc) return rc;
@@ -1354,7 +1377,12 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
 /* can this step ride on fused k_step launches? (run!-style: State zeroed first, static winds) */
 static bool step_fusable(const picles_ctx *c, int flags)
 {
-    return (flags == PICLES_STEP_ZERO_FIRST) && c->P.wind_static && !c->wind_grid_on && c->fuse_steps && !c->A.pc;
+    if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps || c->A.pc) return false;
+    if (c->wind_grid_on) {   /* device-sampled winds: the time-varying flavour exists for the specialised physics */
+        const KParams &P = c->P;
+        return P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+    }
+    return c->P.wind_static != 0;
 }
 
 /* fused phase launcher: scatter+remesh of the pending step and advance of the current one for the
@@ -1375,13 +1403,19 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     bool db = P.deadband2 > 0.0;
     dim3 grid(nblocks(nt, 256)), block(256);
     timing_begin(c, s, 0);
-#define LAUNCH_STEP(F, T, D) hipLaunchKernelGGL((k_step<F, T, D>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
-    if (fast && db && P.solver) LAUNCH_STEP(true, true, true);
-    else if (fast && db) LAUNCH_STEP(true, false, true);
-    else if (fast && P.solver) LAUNCH_STEP(true, true, false);
-    else if (fast) LAUNCH_STEP(true, false, false);
-    else if (P.solver) LAUNCH_STEP(false, true, false);
-    else LAUNCH_STEP(false, false, false);
+#define LAUNCH_STEP(F, T, D, S) hipLaunchKernelGGL((k_step<F, T, D, S>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
+    if (!P.wind_static) {     /* device-sampled winds: specialised physics only (step_fusable) */
+        if (db && P.solver) LAUNCH_STEP(true, true, true, false);
+        else if (db) LAUNCH_STEP(true, false, true, false);
+        else if (P.solver) LAUNCH_STEP(true, true, false, false);
+        else LAUNCH_STEP(true, false, false, false);
+    }
+    else if (fast && db && P.solver) LAUNCH_STEP(true, true, true, true);
+    else if (fast && db) LAUNCH_STEP(true, false, true, true);
+    else if (fast && P.solver) LAUNCH_STEP(true, true, false, true);
+    else if (fast) LAUNCH_STEP(true, false, false, true);
+    else if (P.solver) LAUNCH_STEP(false, true, false, true);
+    else LAUNCH_STEP(false, false, false, true);
 #undef LAUNCH_STEP
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
@@ -1398,6 +1432,35 @@ PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
     if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
     if (!step_fusable(c, PICLES_STEP_ZERO_FIRST)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->wind_grid_on) {
+        /* device-sampled winds.  With a step pending, its remesh (done by this step's launches) needs the wind
+         * at ITS clock: level 0 of its window.  The three level planes rotate — previous level 0 -> (uP, vP),
+         * previous level 1 -> level 0 — and only the new level 1 is sampled. */
+        Arrays &A = c->A;
+        if (c->pending && !(c->wind_t1_valid && c->wind_t1 == c->clock && c->P.tw0 == c->pend_t && !c->P.wind_static))
+            return 1;   /* the windows are not contiguous: take the plain phases (they flush first) */
+        if (c->ext_streams) HIPCHK(c, hipDeviceSynchronize());   /* earlier launches on other streams read the planes */
+        if (c->pending) {
+            if (!A.uP) {
+                HIPCHK(c, hipMalloc(&A.uP, (size_t)A.n * 8));
+                HIPCHK(c, hipMalloc(&A.vP, (size_t)A.n * 8));
+            }
+            double *tu = A.uP, *tv = A.vP;
+            A.uP = A.u0; A.vP = A.v0;
+            A.u0 = A.u1; A.v0 = A.v1;
+            A.u1 = tu; A.v1 = tv;
+            dim3 grid(nblocks(A.n, 256)), block(256);
+            hipLaunchKernelGGL(k_wind_sample, grid, block, 0, c->stream, c->G, c->wg, c->clock + dt, A.u1, A.v1, A.n);
+            HIPCHK(c, hipGetLastError());
+            c->wind_t1 = c->clock + dt;
+            c->P.tw0 = c->clock;
+            c->P.inv_dtw = 1.0 / dt;
+        } else {
+            int rc = wind_grid_prepare(c, c->clock, dt, c->stream);
+            if (rc) return rc;
+        }
+        if (c->ext_streams) HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->step_dt = dt;
     c->step_flags = PICLES_STEP_ZERO_FIRST;
     c->edge_pending = false;
@@ -1411,6 +1474,7 @@ PX_EXPORT int32_t picles_step_rows(picles_ctx *c, int32_t which, void *stream)
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (stream) c->ext_streams = true;
     if (!c->pending) return picles_advance_rows(c, which, stream);   /* first step: nothing to scatter yet */
     return launch_step_rows(c, which, s);
 }

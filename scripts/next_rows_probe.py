@@ -35,7 +35,7 @@ lat = IdealizedWindGrid(lambda x, y, t: 10.0 + 0 * x, lambda x, y, t: 10.0 + 0 *
 cfg = configs.box4096(n=n)
 cfg.model["winds"] = wind_interpolator(lat); cfg.model["winds_static"] = False
 m = WaveGrowth2D(**cfg.model)
-timed("gridded winds sampled on device (unfused path)", m, 10)
+timed("gridded winds sampled on device (fused k_step, time-varying flavour)", m, 10)
 del m
 
 cfg = configs.box4096(n=n)

@@ -59,3 +59,45 @@ def test_device_sampler_bitwise_and_run_matches_oracle():
     u0, v0, u1, v1 = g.backend.get_winds()
     assert_bitwise(u0, w.u(X, Y, 2400.0), "u0 of the last step")
     assert_bitwise(u1, w.u(X, Y, 3000.0), "u1 of the last step")
+
+
+def _calm_lattice():
+    """a lattice whose wind drops below the sqrt(wind_min_squared) gate in a band that moves with time: particles are
+    switched off, re-seeded and switched on again, all with time-varying node winds"""
+    amp = lambda x, t: 0.02 + 0.98 * (0.5 + 0.5 * np.tanh((np.abs(x - 20e3 - 2.0 * t) - 9e3) / 2e3))
+    u = lambda x, y, t: (9.0 + 3.0 * np.cos(t / 3e3)) * amp(x, t)
+    v = lambda x, y, t: (4.0 + 2.0 * np.sin(y / 9e3)) * amp(x, t)
+    return IdealizedWindGrid(u, v, dict(Lx=64e3, Ly=64e3, T=14400.0), dict(dx=2e3, dy=8e3, dt=600.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lattice", ["smooth", "calm_band"])
+def test_unobserved_run_under_device_sampled_winds_is_fused_and_matches_oracle(lattice):
+    """consecutive run!-style steps with NOBODY looking at State in between: the library rotates three wind level
+    planes and runs one fused launch per step (k_step, time-varying flavour) whose remesh reads the wind of the
+    previous window.  Final State, particles and counters must equal the step-by-step oracle bitwise."""
+    lat = _lattice()[0] if lattice == "smooth" else _calm_lattice()
+    w = wind_interpolator(lat)
+    g = make_model(_cfg(w), "hip")
+    o = make_model(_cfg(w), ("pmath", 1))
+    for m in (g, o):
+        initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
+    n = 9
+    g.backend.reset_counters(); g.backend.enable_timing(True)
+    for k in range(n):
+        time_step(o, 600.0, zero_first=True)
+        time_step(g, 600.0, zero_first=True)          # State is not read: the steps stay fused
+    tim = g.backend.get_timing()
+    assert tim["scatter_launches"] <= 2, tim             # only the first step ran the separate scatter launch
+    assert_bitwise(g.State, o.State, "State after the unobserved run")
+    zg, ong, _, stg = g.backend.get_particles()
+    zo, ono, _, sto = o.backend.get_particles()
+    assert_bitwise(ong, ono, "on"); assert_bitwise(stg, sto, "status")
+    st = ((sto & 1) == 1) & (ono == 1)       # the state vector of a switched-off particle is dead storage (unspecified)
+    for c in range(5):
+        assert_bitwise(zg[..., c][st], zo[..., c][st], f"z[{c}]")
+    cg, co = g.backend.get_counters(), o.backend.get_counters()
+    for key in ("particles_advanced", "rhs_evals", "reseeds"):
+        assert cg[key] == co[key], (key, cg[key], co[key])
+    if lattice == "calm_band":
+        assert co["reseeds"] > 0 and (ono == 0).any()
