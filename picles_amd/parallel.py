@@ -187,6 +187,13 @@ class SlabModel:
 
     def upload_winds(self, t, dt):
         rows = (self.j0, self.j1)
+        from .wind_emulator import GriddedWinds
+        if isinstance(self.winds, GriddedWinds) and hasattr(self.backend, "set_wind_grid"):
+            if self._wind_window != "device-lattice":      # once: every slab samples its own rows on the device
+                g = self.grid
+                self.backend.set_wind_grid(self.winds.lattice(), float(g.data.x[0, 0]), float(g.data.y[0, 0]))   # global mesh origin: the sampler adds j_begin
+                self._wind_window = "device-lattice"
+            return
         if self.static:
             if self._wind_window is None:
                 u, v = sample_winds(self.winds, self.grid, t, rows)
