@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * ---------------------------------------------------------------------------------------- */
 /* STATIC = false: winds linear in time over the step window (u0,v0 -> u1,v1); the remesh of the previous step
  * needs the wind at ITS start-of-step clock = level 0 of the previous window, kept in (uP, vP) */
-template <bool FAST, bool TSIT, bool DB, bool STATIC>
+template <bool FAST, bool TSIT, bool DB, bool STATIC, bool METRIC>
 __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
@@ -626,7 +626,9 @@ __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, 
             if (br == 1) { qold = PI_LNQOLDINIT; S.reseeds = 1; }
             unsigned int rs = S.reseeds;
             S.reseeds = 0;
-            int status = advance_particle<FAST, STATIC, false, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S);
+            int status;
+            if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t]);
+            else status = advance_particle<FAST, STATIC, false, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S);
             S.reseeds += rs;
             A.qold[t] = qold;
             A.status[t] = status;
@@ -1377,12 +1379,13 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
 /* can this step ride on fused k_step launches? (run!-style: State zeroed first, static winds) */
 static bool step_fusable(const picles_ctx *c, int flags)
 {
-    if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps || c->A.pc) return false;
-    if (c->wind_grid_on) {   /* device-sampled winds: the time-varying flavour exists for the specialised physics */
-        const KParams &P = c->P;
-        return P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
-    }
-    return c->P.wind_static != 0;
+    if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps) return false;
+    const KParams &P = c->P;
+    const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+    /* the time-varying-wind and per-node-metric flavours of the fused kernel exist for the specialised physics */
+    if (c->wind_grid_on) return fast;
+    if (c->A.pc) return fast && P.wind_static != 0;
+    return P.wind_static != 0;
 }
 
 /* fused phase launcher: scatter+remesh of the pending step and advance of the current one for the
@@ -1403,19 +1406,24 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     bool db = P.deadband2 > 0.0;
     dim3 grid(nblocks(nt, 256)), block(256);
     timing_begin(c, s, 0);
-#define LAUNCH_STEP(F, T, D, S) hipLaunchKernelGGL((k_step<F, T, D, S>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
-    if (!P.wind_static) {     /* device-sampled winds: specialised physics only (step_fusable) */
-        if (db && P.solver) LAUNCH_STEP(true, true, true, false);
-        else if (db) LAUNCH_STEP(true, false, true, false);
-        else if (P.solver) LAUNCH_STEP(true, true, false, false);
-        else LAUNCH_STEP(true, false, false, false);
+#define LAUNCH_STEP(F, T, D, S, M) hipLaunchKernelGGL((k_step<F, T, D, S, M>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
+    if (fast) {     /* specialised physics: solver x dead band x static winds x per-node metric */
+        const int key = (P.solver ? 8 : 0) | (db ? 4 : 0) | (P.wind_static ? 2 : 0) | (c->A.pc ? 1 : 0);
+        switch (key) {
+#define CASE_STEP(k, T, D, S, M) case k: LAUNCH_STEP(true, T, D, S, M); break;
+            CASE_STEP(0, false, false, false, false) CASE_STEP(1, false, false, false, true)
+            CASE_STEP(2, false, false, true, false)  CASE_STEP(3, false, false, true, true)
+            CASE_STEP(4, false, true, false, false)  CASE_STEP(5, false, true, false, true)
+            CASE_STEP(6, false, true, true, false)   CASE_STEP(7, false, true, true, true)
+            CASE_STEP(8, true, false, false, false)  CASE_STEP(9, true, false, false, true)
+            CASE_STEP(10, true, false, true, false)  CASE_STEP(11, true, false, true, true)
+            CASE_STEP(12, true, true, false, false)  CASE_STEP(13, true, true, false, true)
+            CASE_STEP(14, true, true, true, false)   CASE_STEP(15, true, true, true, true)
+#undef CASE_STEP
+        }
     }
-    else if (fast && db && P.solver) LAUNCH_STEP(true, true, true, true);
-    else if (fast && db) LAUNCH_STEP(true, false, true, true);
-    else if (fast && P.solver) LAUNCH_STEP(true, true, false, true);
-    else if (fast) LAUNCH_STEP(true, false, false, true);
-    else if (P.solver) LAUNCH_STEP(false, true, false, true);
-    else LAUNCH_STEP(false, false, false, true);
+    else if (P.solver) LAUNCH_STEP(false, true, false, true, false);      /* general physics: static winds, Cartesian (step_fusable) */
+    else LAUNCH_STEP(false, false, false, true, false);
 #undef LAUNCH_STEP
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());

@@ -52,3 +52,28 @@ def test_sphere_aqua_gpu_bitwise():
         assert_bitwise(a, b, f"State step {k}")
     cg, co = mg.backend.get_counters(), mo.backend.get_counters()
     assert cg["rhs_evals"] == co["rhs_evals"] and cg["max_reach"] == co["max_reach"]
+
+
+@pytest.mark.gpu
+def test_sphere_unobserved_run_is_fused_and_bitwise():
+    """consecutive run!-style steps on the sphere with nobody reading State: one fused launch per step (k_step with
+    the per-node metric flavour); final State and particles equal the step-by-step oracle bitwise"""
+    from picles_amd.simulations import Simulation, initialize_simulation
+    from picles_amd.timesteppers import time_step
+    from helpers import make_model
+    cfg = configs.sphere_aqua(n_steps=8)
+    g, o = make_model(configs.sphere_aqua(n_steps=8), "hip"), make_model(configs.sphere_aqua(n_steps=8), ("pmath", 1))
+    for m in (g, o):
+        initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    g.backend.enable_timing(True)
+    for _ in range(8):
+        time_step(o, cfg.Δt, zero_first=True)
+        time_step(g, cfg.Δt, zero_first=True)
+    assert g.backend.get_timing()["scatter_launches"] <= 2
+    assert_bitwise(g.State, o.State, "State after the unobserved run")
+    zg, ong, _, _ = g.backend.get_particles()
+    zo, ono, _, sto = o.backend.get_particles()
+    assert_bitwise(ong, ono, "on")
+    live = ((sto & 1) == 1) & (ono == 1)
+    for c in range(5):
+        assert_bitwise(zg[..., c][live], zo[..., c][live], f"z[{c}]")
