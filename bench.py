@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--deadband", type=float, default=0.0,
                     help="opt-in picles_phys.dir_deadband (0 = reference-exact RHS; the headline number uses 0)")
-    ap.add_argument("--solver", default="DP5", choices=["DP5", "Tsit5"],
+    ap.add_argument("--solver", default="DP5", choices=["DP5", "Tsit5", "AutoTsit5"],
                     help="ODE solver of the workload (the BASELINE box is quoted on DP5, as benchmarks/bench06 sets it)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")

@@ -65,7 +65,10 @@ typedef struct picles_ode {
     double  dtmin;
     int32_t force_dtmin;
     int32_t solver;          /* 0 = DP5 (Dormand-Prince 5(4), bench06:93); 1 = Tsit5 (the explicit
-                                half of the ODESettings default AutoTsit5(Rosenbrock23()))    */
+                                half of the ODESettings default); 2 = AutoTsit5(Rosenbrock23()),
+                                the ODESettings default itself (particle_waves_v5.jl:47): Tsit5 with
+                                the stiffness test of OrdinaryDiffEq's AutoSwitch and a Rosenbrock23
+                                fallback on an exact hand-written Jacobian (restated, unpinned)   */
     int64_t maxiters;        /* per model step                        */
     double  log_energy_minimum, log_energy_maximum, wind_min_squared;
     double  timestep;        /* ODESettings.timestep: seed time-scale of init_particles!    */

@@ -97,6 +97,7 @@ static const po_tab PO_TSIT5 = {
 #define CTRL_QMAX 10.0
 #define CTRL_QOLDINIT 1e-4
 #define CTRL_LNQOLDINIT (-9.210340371976182) /* ln(1e-4); order 1 carries ln(qold) */
+#define PO_QOLD_RESET(M) (((M)->order || (M)->od.solver == 2) ? CTRL_LNQOLDINIT : CTRL_QOLDINIT)   /* solver 2 always runs the log-space controller */
 
 typedef struct po_consts {
     double p, n, e_T, inv_eT, inv_rg, inv_dx, inv_dy;
@@ -124,6 +125,7 @@ typedef struct po_model {
     double *state, *movie;     /* 3 planes */
     double *z;                 /* 5 planes */
     double *qold, *dtn;        /* controller memory, next dt (<0: auto_dt_reset!) */
+    int32_t *asw;              /* solver 2: AutoSwitch state (po_integrate_auto) */
     uint8_t *on, *bnd;
     int32_t *status;
     int64_t n_step;
@@ -529,8 +531,15 @@ static double po_initdt_kernel(const po_model *M, int64_t idx, const double u0[5
 }
 
 /* One attempted DP5 step of size h from (u0,k1) at absolute time t. Returns EEst. */
+static double po_dp5_try_e(const po_model *M, int64_t idx, const double u0[5], const double k1[5],
+                           double t, double h, double unew[5], double k7[5], po_pstats *st, double *eigen_est);
 static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], const double k1[5],
                          double t, double h, double unew[5], double k7[5], po_pstats *st)
+{
+    return po_dp5_try_e(M, idx, u0, k1, t, h, unew, k7, st, NULL);
+}
+static double po_dp5_try_e(const po_model *M, int64_t idx, const double u0[5], const double k1[5],
+                           double t, double h, double unew[5], double k7[5], po_pstats *st, double *eigen_est)
 {
     const picles_ode *od = &M->od;
     /* tableau of the selected solver (od->solver: 0 DP5, 1 Tsit5); same 7-stage FSAL structure */
@@ -590,30 +599,39 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
     const double ipx = M->ph.propagation ? (M->m11 ? M->m11[idx] : M->k.inv_dx) : 0.0;
     const double ipy = M->ph.propagation ? (M->m22 ? M->m22[idx] : M->k.inv_dy) : 0.0;
 #define XYACC(a7, e) do { sx = PO_FMA(a7, g[1], sx); sy = PO_FMA(a7, g[2], sy); ex = PO_FMA(e, g[1], ex); ey = PO_FMA(e, g[2], ey); } while (0)
+    /* Σ a6j c̄_j: the x,y position of stage 6, needed only for the stiffness estimate of the auto-switching solver */
+    double s6x = A61 * u0[1], s6y = A61 * u0[2];
+#define S6ACC(a6) do { s6x = PO_FMA(a6, g[1], s6x); s6y = PO_FMA(a6, g[2], s6y); } while (0)
     po_wind(M, idx, K ? PO_FMA(C2, h, t) : t + C2 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k2);
     if (K && T->has2) XYACC(A72, E2);
+    S6ACC(A62);
     STAGE(u0[i] + h * (A31 * k1[i] + A32 * k2[i]),
           PO_FMA(h, PO_FMA(A32, k2[i], A31 * k1[i]), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C3, h, t) : t + C3 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k3);
     XYACC(A73, E3);
+    S6ACC(A63);
     STAGE(u0[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]),
           PO_FMA(h, PO_FMA(A43, k3[i], PO_FMA(A42, k2[i], A41 * k1[i])), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C4, h, t) : t + C4 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k4);
     XYACC(A74, E4);
+    S6ACC(A64);
     STAGE(u0[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]),
           PO_FMA(h, PO_FMA(A54, k4[i], PO_FMA(A53, k3[i], PO_FMA(A52, k2[i], A51 * k1[i]))), u0[i]));
     po_wind(M, idx, K ? PO_FMA(C5, h, t) : t + C5 * h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k5);
     XYACC(A75, E5);
+    S6ACC(A65);
     STAGE(u0[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]),
           PO_FMA(h, PO_FMA(A65, k5[i], PO_FMA(A64, k4[i], PO_FMA(A63, k3[i], PO_FMA(A62, k2[i], A61 * k1[i])))), u0[i]));
     po_wind(M, idx, t + h, &uw, &vw);
     po_rhs(M, idx, g, uw, vw, k6);
     XYACC(A76, E6);
 #undef XYACC
+#undef S6ACC
+    const double g6x = PO_FMA(h, s6x * ipx, u0[3]), g6y = PO_FMA(h, s6y * ipy, u0[4]);
     for (int i = 0; i < 5; i++)
         if (K) {
             double s72 = T->has2 ? PO_FMA(A72, k2[i], A71 * k1[i]) : A71 * k1[i];
@@ -627,6 +645,17 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
         }
     po_rhs(M, idx, unew, uw, vw, k7);
     st->rhs += 6;
+    if (eigen_est) {
+        /* Tsit5 inside a CompositeAlgorithm: eigen_est = ||k7 - k6|| / ||u - g6|| (RMS norms over the 5 components);
+         * the x,y components of g6 follow the same stage formula (kernel order: sums on the stage velocities) */
+        double nu = 0.0, nd = 0.0;
+        for (int i = 0; i < 5; i++) {
+            double a = k7[i] - k6[i], b = unew[i] - ((i == 3) ? g6x : (i == 4) ? g6y : g[i]);
+            nu = PO_FMA(a, a, nu);
+            nd = PO_FMA(b, b, nd);
+        }
+        *eigen_est = sqrt(nu / nd);
+    }
 #undef STAGE
     double at[5], sc[5];
     for (int i = 0; i < 5; i++) {
@@ -689,6 +718,296 @@ static double po_dp5_try(const po_model *M, int64_t idx, const double u0[5], con
 #undef E5
 #undef E6
 #undef E7
+}
+
+/* ------------------------------------------------------------------------------------------
+ * solver 2: AutoTsit5(Rosenbrock23()) — the reference's DEFAULT (particle_waves_v5.jl:47).
+ * Third-party semantics restated from OrdinaryDiffEq.jl v6 (unpinned, cannot be run here — "parity unpinned"):
+ *   Tsit5 while the problem looks non-stiff; after every step (accepted or not) the AutoSwitch tests
+ *   |eigen_est * dt_next / 3.5068| > 0.9, with eigen_est = ||k7-k6||/||u-g6|| under Tsit5 and ||J||_inf under
+ *   Rosenbrock23; more than 10 successive positives switch to Rosenbrock23 (dt *= 2), more than 3 successive
+ *   negatives switch back (dt /= 2).  The switch state survives set_u!/auto_dt_reset! (remesh) and is reset by
+ *   reinit! (re-seed).  One PI controller with the order-5 betas (7/50, 2/25) serves both methods.
+ * Rosenbrock23 (Shampine's ode23s as OrdinaryDiffEq writes it), d = 1/(2+sqrt 2), e32 = 6+sqrt 2, g = h d:
+ *   W = I - g J;  k1 = W^-1 (f0 + g dT);  f1 = f(u0 + h/2 k1, t + h/2);  k2 = W^-1 (f1 - k1) + k1;  u = u0 + h k2;
+ *   f2 = f(u, t + h);  k3 = W^-1 (f2 - e32 (k2 - f1) - 2 (k1 - f0) + h dT);  err = h/6 (k1 - 2 k2 + k3).
+ * J = df/du is the exact Jacobian (the reference differentiates with ForwardDiff), written out by hand below for
+ * the kernel-order RHS; dT = df/dt comes from the linear-in-time node wind.  x and y do not feed back, so W is
+ * solved as a 3x3 system (adjugate) plus two substitutions.
+ * ---------------------------------------------------------------------------------------- */
+#define ROS_D 0.29289321881345254   /* 1/(2+sqrt 2) */
+#define ROS_E32 7.414213562373095   /* 6+sqrt 2 */
+#define ASW_STABILITY 3.5068        /* alg_stability_size(Tsit5()) */
+
+/* f (3 components) plus the directional derivatives of f along ns seed directions (dL, dcx, dcy, du, dv) */
+static void po_rhs_jvp(const po_model *M, int64_t idx, const double z[5], double u, double v,
+                       int ns, const double seeds[][5], double f[3], double df[][3])
+{
+    const picles_phys *ph = &M->ph;
+    const po_consts *k = &M->k;
+    const double lne = z[0], cx = z[1], cy = z[2];
+    const double pc = M->pc ? M->pc[idx] : 0.0;
+    /* primal, kernel order (po_rhs_kernel) */
+    double c2 = PO_FMA(cx, cx, cy * cy);
+    double U2 = PO_FMA(u, u, v * v);
+    double y = o_rsqrt(c2);
+    double rc = ph->r_g * y;
+    double ic2 = y * y;
+    double minv = fmin(rc, 10.0);
+    double wp = (0.5 * G0) * minv;
+    double kp = (0.25 * G0) * (minv * minv);
+    double rc2 = rc * rc;
+    double qU2 = 0.25 * U2, invU2 = 1.0 / U2;
+    double a2 = qU2 * rc2;
+    double alpha2 = fmin(a2, 250000.0);
+    double dotc = PO_FMA(u, cx, v * cy);
+    double crsc = u * cy - v * cx;
+    double sginv2 = fmin(rc2, 1e8);
+    double hh = 0.5 * k->inv_rg;
+    double ap = (hh * dotc) * sginv2;
+    double ya = ap - 0.85;
+    double neg2p = -2.0 * k->p;
+    double harg = neg2p * ya;
+    double eH = o_exp((harg > 700.0) ? 700.0 : harg);
+    double hp = 1.0 + eH;
+    double targ = -20.0 * fabs(ya);
+    double t = (targ <= -40.0) ? 0.0 : o_exp(targ);
+    double t1 = 1.0 + t;
+    double t12 = t1 * t1;
+    double rHD = 1.0 / (hp * t12);
+    double H = t12 * rHD;
+    double D = 1.0 - ((5.0 * t) * hp) * rHD;
+    double aH = alpha2 * H;
+    int n_is_2 = (k->n == 2.0);
+    double E2 = o_exp(2.0 * lne);
+    double k2 = kp * kp, k4 = k2 * k2;
+    double Ek = E2 * k4;
+    double ie2 = k->inv_eT * k->inv_eT, ieT4 = ie2 * ie2;
+    double It = ph->input ? ph->C_e * aH : 0.0;
+    double Dt = (ph->dissipation && n_is_2) ? Ek * ieT4 : 0.0;
+    if (ph->dissipation && !n_is_2) Dt = o_exp(k->n * lne) * o_pow(kp * k->inv_eT, 2.0 * k->n);
+    double Scg = ph->peak_shift ? (ph->C_alpha * D) * Ek : 0.0;
+    int calm = (U2 == 0.0 || c2 == 0.0);
+    double K2 = 2.0 * (k->inv_rg * k->inv_rg);
+    double rU = rc2 * invU2;
+    double cd = (K2 * crsc) * dotc;
+    double s2 = calm ? 0.0 : cd * rU;
+    double db2 = ph->dir_deadband * ph->dir_deadband;
+    int dead = (db2 > 0.0 && crsc * crsc <= db2 * (U2 * c2));
+    if (dead) s2 = 0.0;
+    double Sd = ph->direction ? (ph->C_phi * aH) * s2 : 0.0;
+    double wrS = (wp * ph->r_g) * Scg;
+    double Sdm = Sd + (M->pc ? cx * pc : 0.0);
+    f[0] = PO_FMA(wp, It - Dt, wrS);
+    f[1] = PO_FMA(cy, Sdm, -(cx * wrS));
+    f[2] = -PO_FMA(cx, Sdm, cy * wrS);
+    /* tangents */
+    for (int q = 0; q < ns; q++) {
+        const double dL = seeds[q][0], dcx = seeds[q][1], dcy = seeds[q][2], du = seeds[q][3], dv = seeds[q][4];
+        double dc2 = 2.0 * PO_FMA(cx, dcx, cy * dcy);
+        double drc = -0.5 * ((rc * ic2) * dc2);
+        double dminv = (rc <= 10.0) ? drc : 0.0;
+        double dwp = (0.5 * G0) * dminv;
+        double dkp = ((0.5 * G0) * minv) * dminv;
+        double drc2 = 2.0 * (rc * drc);
+        double dU2 = 2.0 * PO_FMA(u, du, v * dv);
+        double dqU2 = 0.25 * dU2;
+        double dinvU2 = -((invU2 * invU2) * dU2);
+        double dalpha2 = (a2 <= 250000.0) ? PO_FMA(qU2, drc2, rc2 * dqU2) : 0.0;
+        double ddot = PO_FMA(u, dcx, v * dcy) + PO_FMA(cx, du, cy * dv);
+        double dcrs = (u * dcy - v * dcx) + (cy * du - cx * dv);
+        double dsg = (rc2 <= 1e8) ? drc2 : 0.0;
+        double dya = hh * PO_FMA(ddot, sginv2, dotc * dsg);
+        double dhp = (harg > 700.0) ? 0.0 : (eH * neg2p) * dya;
+        double sgn = (ya < 0.0) ? 20.0 : -20.0;
+        double dt_ = (t * sgn) * dya;
+        double dH = -((H * H) * dhp);
+        double dD = -5.0 * ((dt_ * (1.0 - t)) / (t12 * t1));
+        double daH = PO_FMA(dalpha2, H, alpha2 * dH);
+        double dEk = (ph->dissipation && n_is_2) || ph->peak_shift ? Ek * PO_FMA(2.0, dL, 4.0 * (dkp / kp)) : 0.0;
+        double dIt = ph->input ? ph->C_e * daH : 0.0;
+        double dDt = (ph->dissipation && n_is_2) ? dEk * ieT4 : 0.0;
+        if (ph->dissipation && !n_is_2) dDt = Dt * PO_FMA(k->n, dL, (2.0 * k->n) * (dkp / kp));
+        double dScg = ph->peak_shift ? ph->C_alpha * PO_FMA(dD, Ek, D * dEk) : 0.0;
+        double ds2 = 0.0;
+        if (!calm && !dead) {
+            double dcd = K2 * PO_FMA(dcrs, dotc, crsc * ddot);
+            double drU = PO_FMA(drc2, invU2, rc2 * dinvU2);
+            ds2 = PO_FMA(dcd, rU, cd * drU);
+        }
+        double dSd = ph->direction ? ph->C_phi * PO_FMA(daH, s2, aH * ds2) : 0.0;
+        if (M->pc) dSd = dSd + dcx * pc;
+        double dwrS = ph->r_g * PO_FMA(dwp, Scg, wp * dScg);
+        df[q][0] = PO_FMA(dwp, It - Dt, wp * (dIt - dDt)) + dwrS;
+        df[q][1] = PO_FMA(dcy, Sdm, cy * dSd) - PO_FMA(dcx, wrS, cx * dwrS);
+        df[q][2] = -(PO_FMA(dcx, Sdm, cx * dSd) + PO_FMA(dcy, wrS, cy * dwrS));
+    }
+}
+
+/* one attempted Rosenbrock23 step of size h from (u0, f0) at absolute time t; returns EEst^2 (kernel-order norm) and
+ * the stiffness estimate ||J||_inf */
+static double po_ros23_try(const po_model *M, int64_t idx, const double u0[5], const double f0[5],
+                           double t, double h, double unew[5], double f2[5], po_pstats *st, double *eigen_est)
+{
+    const picles_ode *od = &M->od;
+    const double ipx = M->ph.propagation ? (M->m11 ? M->m11[idx] : M->k.inv_dx) : 0.0;
+    const double ipy = M->ph.propagation ? (M->m22 ? M->m22[idx] : M->k.inv_dy) : 0.0;
+    double uw, vw, uw1, vw1;
+    po_wind(M, idx, t, &uw, &vw);
+    double dudt = 0.0, dvdt = 0.0;
+    if (!M->wind_static) {
+        double idt = 1.0 / (M->tw1 - M->tw0);
+        dudt = (M->u1[idx] - M->u0[idx]) * idt;
+        dvdt = (M->v1[idx] - M->v0[idx]) * idt;
+    }
+    const double seeds[4][5] = {{1, 0, 0, 0, 0}, {0, 1, 0, 0, 0}, {0, 0, 1, 0, 0}, {0, 0, 0, dudt, dvdt}};
+    double fj[3], dfs[4][3] = {{0}};
+    const int ns = M->wind_static ? 3 : 4;        /* static winds: dT = 0, its terms are not formed at all */
+    po_rhs_jvp(M, idx, u0, uw, vw, ns, seeds, fj, dfs);
+    st->rhs += ns;    /* counted like RHS evaluations (the reference's ForwardDiff pass costs about as much) */
+    /* J[r][c] = d f_r / d u_c */
+    double J[3][3];
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) J[r][c] = dfs[c][r];
+    const double dT[3] = {dfs[3][0], dfs[3][1], dfs[3][2]};
+    {   /* ||J||_inf over the 5 rows (rows x, y hold 1/dx, 1/dy) */
+        double m = 0.0;
+        for (int r = 0; r < 3; r++) {
+            double rs = fabs(J[r][0]) + fabs(J[r][1]) + fabs(J[r][2]);
+            m = fmax(m, rs);
+        }
+        m = fmax(m, fabs(ipx));
+        m = fmax(m, fabs(ipy));
+        *eigen_est = m;
+    }
+    const double g = h * ROS_D;
+    /* W3 = I - g J3 and its inverse (adjugate / determinant) */
+    double W[3][3], A[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) W[r][c] = ((r == c) ? 1.0 : 0.0) - g * J[r][c];
+    A[0][0] = W[1][1] * W[2][2] - W[1][2] * W[2][1];
+    A[0][1] = W[0][2] * W[2][1] - W[0][1] * W[2][2];
+    A[0][2] = W[0][1] * W[1][2] - W[0][2] * W[1][1];
+    A[1][0] = W[1][2] * W[2][0] - W[1][0] * W[2][2];
+    A[1][1] = W[0][0] * W[2][2] - W[0][2] * W[2][0];
+    A[1][2] = W[0][2] * W[1][0] - W[0][0] * W[1][2];
+    A[2][0] = W[1][0] * W[2][1] - W[1][1] * W[2][0];
+    A[2][1] = W[0][1] * W[2][0] - W[0][0] * W[2][1];
+    A[2][2] = W[0][0] * W[1][1] - W[0][1] * W[1][0];
+    double det = PO_FMA(W[0][0], A[0][0], PO_FMA(W[0][1], A[1][0], W[0][2] * A[2][0]));
+    double idet = 1.0 / det;
+#define WSOLVE(b, out) do { \
+        double q0 = PO_FMA(A[0][0], (b)[0], PO_FMA(A[0][1], (b)[1], A[0][2] * (b)[2])) * idet; \
+        double q1 = PO_FMA(A[1][0], (b)[0], PO_FMA(A[1][1], (b)[1], A[1][2] * (b)[2])) * idet; \
+        double q2 = PO_FMA(A[2][0], (b)[0], PO_FMA(A[2][1], (b)[1], A[2][2] * (b)[2])) * idet; \
+        (out)[0] = q0; (out)[1] = q1; (out)[2] = q2; \
+        (out)[3] = PO_FMA(g * ipx, q1, (b)[3]); (out)[4] = PO_FMA(g * ipy, q2, (b)[4]); } while (0)
+    double b[5], k1[5], k2[5], k3[5], f1[5], us[5];
+    for (int i = 0; i < 3; i++) b[i] = M->wind_static ? f0[i] : PO_FMA(g, dT[i], f0[i]);
+    b[3] = f0[3]; b[4] = f0[4];
+    WSOLVE(b, k1);
+    const double h2 = 0.5 * h;
+    for (int i = 0; i < 5; i++) us[i] = PO_FMA(h2, k1[i], u0[i]);
+    po_wind(M, idx, t + h2, &uw1, &vw1);
+    po_rhs(M, idx, us, uw1, vw1, f1);
+    for (int i = 0; i < 5; i++) b[i] = f1[i] - k1[i];
+    WSOLVE(b, k2);
+    for (int i = 0; i < 5; i++) k2[i] = k2[i] + k1[i];
+    for (int i = 0; i < 5; i++) unew[i] = PO_FMA(h, k2[i], u0[i]);
+    po_wind(M, idx, t + h, &uw1, &vw1);
+    po_rhs(M, idx, unew, uw1, vw1, f2);
+    st->rhs += 2;
+    for (int i = 0; i < 5; i++) {
+        b[i] = (f2[i] - ROS_E32 * (k2[i] - f1[i])) - 2.0 * (k1[i] - f0[i]);
+        if (i < 3 && !M->wind_static) b[i] = b[i] + h * dT[i];
+    }
+    WSOLVE(b, k3);
+#undef WSOLVE
+    double at[5], sc[5];
+    const double h6 = h * (1.0 / 6.0);
+    for (int i = 0; i < 5; i++) {
+        at[i] = h6 * ((k1[i] - 2.0 * k2[i]) + k3[i]);
+        sc[i] = PO_FMA(fmax(fabs(u0[i]), fabs(unew[i])), od->reltol, od->abstol);
+    }
+    double p2 = sc[0] * sc[1], p3 = p2 * sc[2], p4 = p3 * sc[3], pp = p4 * sc[4];
+    double q2 = sc[3] * sc[4], q1 = sc[2] * q2, q0 = sc[1] * q1;
+    double n0 = at[0] * q0, n1 = (at[1] * sc[0]) * q1, n2 = (at[2] * p2) * q2;
+    double n3 = (at[3] * p3) * sc[4], n4 = at[4] * p4;
+    double S = n0 * n0;
+    S = PO_FMA(n1, n1, S);
+    S = PO_FMA(n2, n2, S);
+    S = PO_FMA(n3, n3, S);
+    S = PO_FMA(n4, n4, S);
+    double rp = 1.0 / pp;
+    return (S * 0.2) * (rp * rp);
+}
+
+/* step!(integrator, DT, true) for solver 2 (AutoTsit5(Rosenbrock23())): PI controller in log space as in the kernel
+ * order; *asw carries the AutoSwitch state across model steps: bit 0 = Rosenbrock23 active, the rest = the signed
+ * counter of successive stiffness-test outcomes, bit 30 of the counter part unused; *asw == INT32_MIN = "fresh". */
+#define ASW_FRESH INT32_MIN
+static void po_integrate_auto(const po_model *M, int64_t idx, double z[5], double *qold, double *dtn, int32_t *asw,
+                              double t_start, double DT, po_pstats *st)
+{
+    const picles_ode *od = &M->od;
+    double k1[5], kn[5], unew[5], uw, vw;
+    double tr = 0.0;
+    po_wind(M, idx, t_start, &uw, &vw);
+    po_rhs(M, idx, z, uw, vw, k1);
+    st->rhs++;
+    int fresh = (*asw == ASW_FRESH);
+    int stiff = fresh ? 0 : (*asw & 1);
+    int count = fresh ? 0 : (*asw >> 1);
+    double dt = *dtn;
+    if (!(dt > 0.0)) {
+        dt = po_initdt(M, idx, z, k1, t_start, st);
+    }
+    const double beta1 = 0.14, beta2 = 0.08;
+    double eig = 0.0;
+    int have_eig = 0;
+    int64_t iter = 0;
+    while (tr < DT) {
+        iter++;
+        if (iter > od->maxiters) { st->status |= PICLES_ST_MAXITERS; break; }
+        /* choose_algorithm! (loopheader!): the test uses the estimate of the previous attempt and the proposed dt */
+        if (fresh) {
+            fresh = 0;                 /* first call: current = nonstiff, no test */
+        } else if (have_eig) {
+            int pos = fabs(eig * dt * (1.0 / ASW_STABILITY)) > 0.9;
+            count = pos ? (count < 0 ? 1 : count + 1) : (count > 0 ? -1 : count - 1);
+            if (!stiff && count > 10) { dt = dt * 2.0; stiff = 1; }
+            else if (stiff && count < -3) { dt = dt * 0.5; stiff = 0; }
+        }
+        if (dt < od->dtmin) dt = od->dtmin;
+        double rem = DT - tr;
+        double h = (dt < rem) ? dt : rem;
+        int last = !(dt < rem);
+        double EE2;
+        if (stiff) EE2 = po_ros23_try(M, idx, z, k1, t_start + tr, h, unew, kn, st, &eig);
+        else EE2 = po_dp5_try_e(M, idx, z, k1, t_start + tr, h, unew, kn, st, &eig);
+        have_eig = 1;
+        if (!M->order && !stiff) EE2 = EE2 * EE2;     /* the literal-order explicit pair returns EEst; Rosenbrock returns EEst² */
+        if (!(eig == eig)) eig = 0.0;
+        if (!(EE2 == EE2)) { EE2 = INFINITY; st->status |= PICLES_ST_NONFINITE; }
+        int accept = (EE2 <= 1.0) || (od->force_dtmin && h <= od->dtmin);
+        double le = 0.5 * o_log_coarse(EE2);
+        if (accept) {
+            st->acc++;
+            double qi = o_exp(PO_FMA(beta2, *qold, -(beta1 * le))) * CTRL_GAMMA;
+            qi = fmax(fmin(qi, CTRL_QMAX), CTRL_QMIN);
+            *qold = fmax(le, CTRL_LNQOLDINIT);
+            dt = h * qi;
+            for (int i = 0; i < 5; i++) { z[i] = unew[i]; k1[i] = kn[i]; }
+            tr = last ? DT : tr + h;
+            if (z[0] != z[0] || z[1] != z[1] || z[2] != z[2] || z[3] != z[3] || z[4] != z[4]) break;
+        } else {
+            st->rej++;
+            double r = CTRL_GAMMA * o_exp(-(beta1 * le));
+            r = fmax(r, CTRL_QMIN);
+            dt = h * r;
+            if (!od->force_dtmin && h <= od->dtmin) { st->status |= PICLES_ST_DTMIN; break; }
+        }
+    }
+    *dtn = dt;
+    *asw = (int32_t)((uint32_t)count << 1) | stiff;
 }
 
 /* step!(integrator, DT, true): integrate particle idx from clock to clock+DT. */
@@ -834,7 +1153,8 @@ static void po_advance_particle(po_model *M, int64_t idx, double DT, po_pstats *
     int status = PICLES_ST_STEPPED;
     if (M->on[idx]) {
         po_pstats s = {0, 0, 0, 0};
-        po_integrate(M, idx, z, &M->qold[idx], &M->dtn[idx], t_start, DT, &s);
+        if (M->od.solver == 2) po_integrate_auto(M, idx, z, &M->qold[idx], &M->dtn[idx], &M->asw[idx], t_start, DT, &s);
+        else po_integrate(M, idx, z, &M->qold[idx], &M->dtn[idx], t_start, DT, &s);
         st->rhs += s.rhs; st->acc += s.acc; st->rej += s.rej;
         status |= s.status;
     } else {
@@ -885,7 +1205,8 @@ static void po_remesh_particle(po_model *M, int64_t idx, double DT)
     } else if (u * u + v * v >= M->od.wind_min_squared) {                   /* B :328-336, C :338-344 */
         po_reseed(M, u, v, DT, z);
         for (int k = 0; k < 5; k++) M->z[idx + k * M->N] = z[k];
-        M->qold[idx] = M->order ? CTRL_LNQOLDINIT : CTRL_QOLDINIT;   /* reinit! resets the controller */
+        M->qold[idx] = PO_QOLD_RESET(M);   /* reinit! resets the controller */
+        M->asw[idx] = INT32_MIN;           /* ... and the AutoSwitch state */
         M->dtn[idx] = -1.0;
         M->on[idx] = 1;
         __atomic_fetch_add(&M->cnt.reseeds, 1, __ATOMIC_RELAXED);
@@ -939,6 +1260,7 @@ PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *
     M->movie = (double *)calloc(3 * N, 8);
     M->z = (double *)calloc(5 * N, 8);
     M->qold = (double *)calloc(N, 8);
+    M->asw = (int32_t *)calloc(N, 4);
     M->dtn = (double *)calloc(N, 8);
     M->on = (uint8_t *)calloc(N, 1);
     M->bnd = (uint8_t *)calloc(N, 1);
@@ -964,7 +1286,7 @@ PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *
 PO_EXPORT int32_t picles_oracle_destroy(po_model *M)
 {
     if (!M) return 0;
-    free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->dtn); free(M->grp); free(M->rec);
+    free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->asw); free(M->dtn); free(M->grp); free(M->rec);
     free(M->on); free(M->bnd); free(M->status); free(M->steplist);
     free(M->u0); free(M->v0); free(M->u1); free(M->v1);
     free(M->m11); free(M->m22); free(M->pc);
@@ -1017,7 +1339,8 @@ PO_EXPORT int32_t picles_oracle_seed(po_model *M, double t0)
     memset(&M->cnt, 0, sizeof(M->cnt));
     for (int64_t n = 0; n < N; n++) {
         M->status[n] = 0;
-        M->qold[n] = M->order ? CTRL_LNQOLDINIT : CTRL_QOLDINIT;
+        M->qold[n] = PO_QOLD_RESET(M);
+        M->asw[n] = INT32_MIN;
         M->dtn[n] = M->od.dt0;
         for (int c = 0; c < 5; c++) M->z[n + c * N] = 0.0;
         M->on[n] = 0;
@@ -1366,6 +1689,23 @@ PO_EXPORT int32_t picles_oracle_integrate(po_model *M, int64_t idx, double z[5],
     po_integrate(M, idx, z, qold, dtn, t_start, DT, &st);
     stats[0] = st.rhs; stats[1] = st.acc; stats[2] = st.rej;
     return st.status;
+}
+PO_EXPORT int32_t picles_oracle_integrate_auto(po_model *M, int64_t idx, double z[5], double *qold, double *dtn, int32_t *asw,
+                                               double t_start, double DT, uint64_t stats[3])
+{
+    po_pstats st = {0, 0, 0, 0};
+    po_integrate_auto(M, idx, z, qold, dtn, asw, t_start, DT, &st);
+    stats[0] = st.rhs; stats[1] = st.acc; stats[2] = st.rej;
+    return st.status;
+}
+/* f and one directional derivative of the RHS (test hook for the hand-written Jacobian) */
+PO_EXPORT void picles_oracle_rhs_jvp(po_model *M, const double z[5], double u, double v, const double seed[5],
+                                     double f[3], double df[3])
+{
+    const double seeds[1][5] = {{seed[0], seed[1], seed[2], seed[3], seed[4]}};
+    double d[1][3];
+    po_rhs_jvp(M, 0, z, u, v, 1, seeds, f, d);
+    df[0] = d[0][0]; df[1] = d[0][1]; df[2] = d[0][2];
 }
 PO_EXPORT int32_t picles_oracle_is_pmath(void)
 {

@@ -372,6 +372,209 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     d.cy = -PM_FMA(cx, Sd, cy * wrS);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * solver 2 = AutoTsit5(Rosenbrock23()), the reference's default (particle_waves_v5.jl:47); semantics restated
+ * from OrdinaryDiffEq.jl (unpinned; the full statement of the semantics is in DESIGN.md §2 and above integrate_dp5).
+ * rhs3_jvp: directional derivatives of the kernel-order RHS along NS seed directions
+ * (d lne, d c̄x, d c̄y, du, dv) — the exact Jacobian (and ∂f/∂t through the node wind) written out by hand.
+ * ---------------------------------------------------------------------------------------- */
+#define ROS_D 0.29289321881345254   /* 1/(2+sqrt 2) */
+#define ROS_E32 7.414213562373095   /* 6+sqrt 2 */
+#define ASW_STABILITY 3.5068        /* alg_stability_size(Tsit5()) */
+#define ASW_FRESH (-2147483647 - 1)
+
+struct Seed5 {
+    double dL, dcx, dcy, du, dv;
+};
+
+template <bool FAST, bool METRIC, bool DB, int NS>
+PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const WindD &W, double pc,
+                    const Seed5 (&seeds)[NS], Vec3 (&df)[NS])
+{
+    const double u = W.u, v = W.v;
+    double c2 = PM_FMA(cx, cx, cy * cy);
+    double y = pm_rsqrt(c2);
+    double rc = P.r_g * y;
+    double ic2 = y * y;
+    double minv = pm_fmin(rc, 10.0);
+    double wp = (0.5 * PK_G0) * minv;
+    double kp = (0.25 * PK_G0) * (minv * minv);
+    double rc2 = rc * rc;
+    double a2 = W.qU2 * rc2;
+    double alpha2 = pm_fmin(a2, 250000.0);
+    double dotc = PM_FMA(u, cx, v * cy);
+    double crsc = u * cy - v * cx;
+    double sginv2 = pm_fmin(rc2, 1e8);
+    double ap = (P.half_inv_rg * dotc) * sginv2;
+    double ya = ap - 0.85;
+    double harg = P.neg2p * ya;
+    double eH = pm_exp((harg > 700.0) ? 700.0 : harg);
+    double hp = 1.0 + eH;
+    double targ = -20.0 * pm_fabs(ya);
+    double t = (targ <= -40.0) ? 0.0 : pm_exp(targ);
+    double t1 = 1.0 + t;
+    double t12 = t1 * t1;
+    double rHD = 1.0 / (hp * t12);
+    double H = t12 * rHD;
+    double D = 1.0 - ((5.0 * t) * hp) * rHD;
+    double aH = alpha2 * H;
+    const bool n2 = FAST || P.n_is_2;
+    const bool s_in = FAST || P.input, s_di = FAST || P.dissipation, s_ps = FAST || P.peak_shift, s_dr = FAST || P.direction;
+    double E2 = pm_exp(2.0 * lne);
+    double k2 = kp * kp, k4 = k2 * k2;
+    double Ek = E2 * k4;
+    double It = s_in ? P.C_e * aH : 0.0;
+    double Dt = (s_di && n2) ? Ek * P.inv_eT4 : 0.0;
+    if (s_di && !n2) Dt = pm_exp(P.n * lne) * pm_pow(kp * P.inv_eT, 2.0 * P.n);
+    double Scg = s_ps ? (P.C_alpha * D) * Ek : 0.0;
+    bool calm = (W.U2 == 0.0 || c2 == 0.0);
+    double rU = rc2 * W.invU2;
+    double cd = (P.two_inv_rg2 * crsc) * dotc;
+    double s2 = calm ? 0.0 : cd * rU;
+    bool dead = (DB || !FAST) && (P.deadband2 > 0.0 && crsc * crsc <= P.deadband2 * (W.U2 * c2));
+    if (dead) s2 = 0.0;
+    double Sd = s_dr ? (P.C_phi * aH) * s2 : 0.0;
+    double wrS = (wp * P.r_g) * Scg;
+    double Sdm = Sd + (METRIC ? cx * pc : 0.0);
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+        const double dL = seeds[q].dL, dcx = seeds[q].dcx, dcy = seeds[q].dcy, du = seeds[q].du, dv = seeds[q].dv;
+        double dc2 = 2.0 * PM_FMA(cx, dcx, cy * dcy);
+        double drc = -0.5 * ((rc * ic2) * dc2);
+        double dminv = (rc <= 10.0) ? drc : 0.0;
+        double dwp = (0.5 * PK_G0) * dminv;
+        double dkp = ((0.5 * PK_G0) * minv) * dminv;
+        double drc2 = 2.0 * (rc * drc);
+        double dU2 = 2.0 * PM_FMA(u, du, v * dv);
+        double dqU2 = 0.25 * dU2;
+        double dinvU2 = -((W.invU2 * W.invU2) * dU2);
+        double dalpha2 = (a2 <= 250000.0) ? PM_FMA(W.qU2, drc2, rc2 * dqU2) : 0.0;
+        double ddot = PM_FMA(u, dcx, v * dcy) + PM_FMA(cx, du, cy * dv);
+        double dcrs = (u * dcy - v * dcx) + (cy * du - cx * dv);
+        double dsg = (rc2 <= 1e8) ? drc2 : 0.0;
+        double dya = P.half_inv_rg * PM_FMA(ddot, sginv2, dotc * dsg);
+        double dhp = (harg > 700.0) ? 0.0 : (eH * P.neg2p) * dya;
+        double sgn = (ya < 0.0) ? 20.0 : -20.0;
+        double dt_ = (t * sgn) * dya;
+        double dH = -((H * H) * dhp);
+        double dD = -5.0 * ((dt_ * (1.0 - t)) / (t12 * t1));
+        double daH = PM_FMA(dalpha2, H, alpha2 * dH);
+        double dEk = ((s_di && n2) || s_ps) ? Ek * PM_FMA(2.0, dL, 4.0 * (dkp / kp)) : 0.0;
+        double dIt = s_in ? P.C_e * daH : 0.0;
+        double dDt = (s_di && n2) ? dEk * P.inv_eT4 : 0.0;
+        if (s_di && !n2) dDt = Dt * PM_FMA(P.n, dL, (2.0 * P.n) * (dkp / kp));
+        double dScg = s_ps ? P.C_alpha * PM_FMA(dD, Ek, D * dEk) : 0.0;
+        double ds2 = 0.0;
+        if (!calm && !dead) {
+            double dcd = P.two_inv_rg2 * PM_FMA(dcrs, dotc, crsc * ddot);
+            double drU = PM_FMA(drc2, W.invU2, rc2 * dinvU2);
+            ds2 = PM_FMA(dcd, rU, cd * drU);
+        }
+        double dSd = s_dr ? P.C_phi * PM_FMA(daH, s2, aH * ds2) : 0.0;
+        if (METRIC) dSd = dSd + dcx * pc;
+        double dwrS = P.r_g * PM_FMA(dwp, Scg, wp * dScg);
+        df[q].lne = PM_FMA(dwp, It - Dt, wp * (dIt - dDt)) + dwrS;
+        df[q].cx = PM_FMA(dcy, Sdm, cy * dSd) - PM_FMA(dcx, wrS, cx * dwrS);
+        df[q].cy = -(PM_FMA(dcx, Sdm, cx * dSd) + PM_FMA(dcy, wrS, cy * dwrS));
+    }
+}
+
+/* one attempted Rosenbrock23 step of size h from (z, f0) at absolute time t: returns EEst² (kernel-order norm),
+ * un = the new state, f2 = f(un, t+h) (the next step's FSAL), eig = ||J||_inf */
+template <bool FAST, bool STATIC, bool METRIC, bool DB>
+PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z, const Vec3 &f0, double t, double h,
+                       double ipx, double ipy, double pc, Vec5 &un, Vec3 &f2, double &eig, PStats &st)
+{
+    constexpr int NS = STATIC ? 3 : 4;
+    Seed5 seeds[NS];
+    Vec3 dfs[NS];
+    seeds[0] = {1.0, 0.0, 0.0, 0.0, 0.0};
+    seeds[1] = {0.0, 1.0, 0.0, 0.0, 0.0};
+    seeds[2] = {0.0, 0.0, 1.0, 0.0, 0.0};
+    if (!STATIC) seeds[NS - 1] = {0.0, 0.0, 0.0, w.du * P.inv_dtw, w.dv * P.inv_dtw};
+    const bool tv = !STATIC && !P.wind_static;   /* a time-varying instantiation may run with static winds: no dT terms then */
+    wind_stage<STATIC>(P, w, t, W);
+    rhs3_jvp<FAST, METRIC, DB, NS>(P, z.lne, z.cx, z.cy, W, pc, seeds, dfs);
+    st.rhs += tv ? 4 : 3;
+    /* J[r][c] = d f_r / d u_c = dfs[c].r */
+    const double J00 = dfs[0].lne, J01 = dfs[1].lne, J02 = dfs[2].lne;
+    const double J10 = dfs[0].cx, J11 = dfs[1].cx, J12 = dfs[2].cx;
+    const double J20 = dfs[0].cy, J21 = dfs[1].cy, J22 = dfs[2].cy;
+    {
+        double m = 0.0;
+        m = pm_fmax(m, (pm_fabs(J00) + pm_fabs(J01)) + pm_fabs(J02));
+        m = pm_fmax(m, (pm_fabs(J10) + pm_fabs(J11)) + pm_fabs(J12));
+        m = pm_fmax(m, (pm_fabs(J20) + pm_fabs(J21)) + pm_fabs(J22));
+        m = pm_fmax(m, pm_fabs(ipx));
+        m = pm_fmax(m, pm_fabs(ipy));
+        eig = m;
+    }
+    const double g = h * ROS_D;
+    const double W00 = 1.0 - g * J00, W01 = 0.0 - g * J01, W02 = 0.0 - g * J02;
+    const double W10 = 0.0 - g * J10, W11 = 1.0 - g * J11, W12 = 0.0 - g * J12;
+    const double W20 = 0.0 - g * J20, W21 = 0.0 - g * J21, W22 = 1.0 - g * J22;
+    const double A00 = W11 * W22 - W12 * W21, A01 = W02 * W21 - W01 * W22, A02 = W01 * W12 - W02 * W11;
+    const double A10 = W12 * W20 - W10 * W22, A11 = W00 * W22 - W02 * W20, A12 = W02 * W10 - W00 * W12;
+    const double A20 = W10 * W21 - W11 * W20, A21 = W01 * W20 - W00 * W21, A22 = W00 * W11 - W01 * W10;
+    const double det = PM_FMA(W00, A00, PM_FMA(W01, A10, W02 * A20));
+    const double idet = 1.0 / det;
+    const double gx = g * ipx, gy = g * ipy;
+#define WSOLVE(b0, b1, b2, b3, b4, o)                                   \
+    do {                                                                \
+        double q0 = PM_FMA(A00, (b0), PM_FMA(A01, (b1), A02 * (b2))) * idet; \
+        double q1 = PM_FMA(A10, (b0), PM_FMA(A11, (b1), A12 * (b2))) * idet; \
+        double q2 = PM_FMA(A20, (b0), PM_FMA(A21, (b1), A22 * (b2))) * idet; \
+        o.lne = q0; o.cx = q1; o.cy = q2;                               \
+        o.x = PM_FMA(gx, q1, (b3)); o.y = PM_FMA(gy, q2, (b4));          \
+    } while (0)
+    const double f0x = z.cx * ipx, f0y = z.cy * ipy;
+    Vec3 dT = {0.0, 0.0, 0.0};
+    if (tv) dT = dfs[NS - 1];
+    Vec5 k1, k2, k3;
+    if (!tv) WSOLVE(f0.lne, f0.cx, f0.cy, f0x, f0y, k1);
+    else WSOLVE(PM_FMA(g, dT.lne, f0.lne), PM_FMA(g, dT.cx, f0.cx), PM_FMA(g, dT.cy, f0.cy), f0x, f0y, k1);
+    const double h2 = 0.5 * h;
+    const double sl = PM_FMA(h2, k1.lne, z.lne), sx = PM_FMA(h2, k1.cx, z.cx), sy = PM_FMA(h2, k1.cy, z.cy);
+    Vec3 f1;
+    wind_stage<STATIC>(P, w, t + h2, W);
+    rhs3<FAST, METRIC, DB>(P, sl, sx, sy, W, f1, pc);
+    const double f1x = sx * ipx, f1y = sy * ipy;
+    WSOLVE(f1.lne - k1.lne, f1.cx - k1.cx, f1.cy - k1.cy, f1x - k1.x, f1y - k1.y, k2);
+    k2.lne = k2.lne + k1.lne; k2.cx = k2.cx + k1.cx; k2.cy = k2.cy + k1.cy; k2.x = k2.x + k1.x; k2.y = k2.y + k1.y;
+    un.lne = PM_FMA(h, k2.lne, z.lne); un.cx = PM_FMA(h, k2.cx, z.cx); un.cy = PM_FMA(h, k2.cy, z.cy);
+    un.x = PM_FMA(h, k2.x, z.x); un.y = PM_FMA(h, k2.y, z.y);
+    wind_stage<STATIC>(P, w, t + h, W);
+    rhs3<FAST, METRIC, DB>(P, un.lne, un.cx, un.cy, W, f2, pc);
+    st.rhs += 2;
+    const double f2x = un.cx * ipx, f2y = un.cy * ipy;
+#define ROSB(F2, K2, F1, K1, F0) (((F2) - ROS_E32 * ((K2) - (F1))) - 2.0 * ((K1) - (F0)))
+    double b0 = ROSB(f2.lne, k2.lne, f1.lne, k1.lne, f0.lne), b1 = ROSB(f2.cx, k2.cx, f1.cx, k1.cx, f0.cx);
+    double b2 = ROSB(f2.cy, k2.cy, f1.cy, k1.cy, f0.cy);
+    double b3 = ROSB(f2x, k2.x, f1x, k1.x, f0x), b4 = ROSB(f2y, k2.y, f1y, k1.y, f0y);
+#undef ROSB
+    if (tv) { b0 = b0 + h * dT.lne; b1 = b1 + h * dT.cx; b2 = b2 + h * dT.cy; }
+    WSOLVE(b0, b1, b2, b3, b4, k3);
+#undef WSOLVE
+    const double h6 = h * (1.0 / 6.0);
+#define ROSE(c) (h6 * ((k1.c - 2.0 * k2.c) + k3.c))
+#define ERRS(a, b) PM_FMA(pm_fmax(pm_fabs(a), pm_fabs(b)), P.reltol, P.abstol)
+    double s0 = ERRS(z.lne, un.lne), s1 = ERRS(z.cx, un.cx), s2 = ERRS(z.cy, un.cy);
+    double s3 = ERRS(z.x, un.x), s4 = ERRS(z.y, un.y);
+    double p2 = s0 * s1, p3 = p2 * s2, p4 = p3 * s3, pp = p4 * s4;
+    double q2 = s3 * s4, q1 = s2 * q2, q0 = s1 * q1;
+    double n0 = ROSE(lne) * q0, n1 = (ROSE(cx) * s0) * q1, n2 = (ROSE(cy) * p2) * q2;
+    double n3 = (ROSE(x) * p3) * s4, n4 = ROSE(y) * p4;
+#undef ROSE
+#undef ERRS
+    double S = n0 * n0;
+    S = PM_FMA(n1, n1, S);
+    S = PM_FMA(n2, n2, S);
+    S = PM_FMA(n3, n3, S);
+    S = PM_FMA(n4, n4, S);
+    double rp = 1.0 / pp;
+    return (S * 0.2) * (rp * rp);
+}
+
 /* mean square of five numbers (the squared RMS norm) */
 PM_HD double ms5(double a0, double a1, double a2, double a3, double a4)
 {
@@ -447,9 +650,13 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
 /* step!(integrator, DT, true): integrate z over [t_start, t_start+DT] with DP5(4).
  * Only the stage derivatives of (lne, c̄x, c̄y) are kept; the x,y rows of the tableau are
  * accumulated as the stages appear (same fma order as the full Butcher sums). */
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false>
+/* AUTO (solver 2, implies TSIT): AutoTsit5(Rosenbrock23()) — after every attempt the AutoSwitch tests
+ * |eigen_est·dt_next/3.5068| > 0.9; more than 10 successive positives hand over to Rosenbrock23 (dt·2), more than 3
+ * successive negatives hand back (dt/2).  *asw carries (counter << 1 | rosenbrock_active) across model steps. */
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false, bool AUTO = false>
 PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, double &dtn,
-                         double t_start, double DT, PStats &st, double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
+                         double t_start, double DT, PStats &st, double m11 = 0.0, double m22 = 0.0, double pc = 0.0,
+                         int *asw = nullptr)
 {
     /* projection M = diag(ipx, ipy): 1/Δx, 1/Δy on the Cartesian mesh, per node otherwise */
     const double ipx = (FAST || P.propagation) ? (METRIC ? m11 : P.inv_dx) : 0.0;
@@ -467,20 +674,46 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     double dt = dtn;
     if (!(dt > 0.0)) dt = init_dt<FAST, STATIC, METRIC, DB>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, pc, t_start, st);
     long long iter = 0;
+    bool as_fresh = false, as_stiff = false, have_eig = false;
+    int as_count = 0;
+    double eig = 0.0;
+    if (AUTO) {
+        as_fresh = (*asw == ASW_FRESH);
+        as_stiff = as_fresh ? false : ((*asw & 1) != 0);
+        as_count = as_fresh ? 0 : (*asw >> 1);
+    }
     while (tr < DT) {
         iter++;
         if (iter > P.maxiters) { st.status |= 2 /*PICLES_ST_MAXITERS*/; break; }
+        if (AUTO) {   /* choose_algorithm!: the estimate of the previous attempt against the proposed dt */
+            if (as_fresh) {
+                as_fresh = false;
+            } else if (have_eig) {
+                bool pos = pm_fabs(eig * dt * (1.0 / ASW_STABILITY)) > 0.9;
+                as_count = pos ? (as_count < 0 ? 1 : as_count + 1) : (as_count > 0 ? -1 : as_count - 1);
+                if (!as_stiff && as_count > 10) { dt = dt * 2.0; as_stiff = true; }
+                else if (as_stiff && as_count < -3) { dt = dt * 0.5; as_stiff = false; }
+            }
+        }
         if (dt < P.dtmin) dt = P.dtmin;
         double rem = DT - tr;
         bool last = !(dt < rem);
         double h = last ? rem : dt;
         double t = t_start + tr;
+        Vec5 un;
+        double EE2;
+        if (AUTO && as_stiff) {
+            EE2 = ros23_try<FAST, STATIC, METRIC, DB>(P, w, W, z, k1, t, h, ipx, ipy, pc, un, k7, eig, st);
+        } else {
         double gl, gx, gy;      /* stage state (lne, c̄x, c̄y) */
         /* x,y tendencies are c̄x/Δx, c̄y/Δy of the stage state: their tableau sums run on the stage
          * c̄ itself (Σ a7i c̄_i, Σ e_i c̄_i) and meet the projection 1/Δx, 1/Δy once, at the end */
         double ax, ay, ex, ey;
         ax = TT(a71) * z.cx; ay = TT(a71) * z.cy;
         ex = TT(e1) * z.cx; ey = TT(e1) * z.cy;
+        double s6x = 0.0, s6y = 0.0;   /* AUTO: Σ a6j c̄_j, the x,y position of stage 6 (stiffness estimate) */
+        if (AUTO) { s6x = TT(a61) * z.cx; s6y = TT(a61) * z.cy; }
+#define S6ACC(a6) do { if (AUTO) { s6x = PM_FMA(TT(a6), gx, s6x); s6y = PM_FMA(TT(a6), gy, s6y); } } while (0)
         {
             double a21h = h * TT(a21);
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
@@ -491,24 +724,29 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             ax = PM_FMA(TT(a72), gx, ax); ay = PM_FMA(TT(a72), gy, ay);
             ex = PM_FMA(TT(e2), gx, ex); ey = PM_FMA(TT(e2), gy, ey);
         }
+        S6ACC(a62);
 #define ST3(c) PM_FMA(h, PM_FMA(TT(a32), k2.c, TT(a31) * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c3), h, t), W);
         rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k3, pc);
         ax = PM_FMA(TT(a73), gx, ax); ay = PM_FMA(TT(a73), gy, ay);
         ex = PM_FMA(TT(e3), gx, ex); ey = PM_FMA(TT(e3), gy, ey);
+        S6ACC(a63);
 #define ST4(c) PM_FMA(h, PM_FMA(TT(a43), k3.c, PM_FMA(TT(a42), k2.c, TT(a41) * k1.c)), z.c)
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c4), h, t), W);
         rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k4, pc);
         ax = PM_FMA(TT(a74), gx, ax); ay = PM_FMA(TT(a74), gy, ay);
         ex = PM_FMA(TT(e4), gx, ex); ey = PM_FMA(TT(e4), gy, ey);
+        S6ACC(a64);
 #define ST5(c) PM_FMA(h, PM_FMA(TT(a54), k4.c, PM_FMA(TT(a53), k3.c, PM_FMA(TT(a52), k2.c, TT(a51) * k1.c))), z.c)
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c5), h, t), W);
         rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k5, pc);
         ax = PM_FMA(TT(a75), gx, ax); ay = PM_FMA(TT(a75), gy, ay);
         ex = PM_FMA(TT(e5), gx, ex); ey = PM_FMA(TT(e5), gy, ey);
+        S6ACC(a65);
+#undef S6ACC
 #define ST6(c) PM_FMA(h, PM_FMA(TT(a65), k5.c, PM_FMA(TT(a64), k4.c, PM_FMA(TT(a63), k3.c, PM_FMA(TT(a62), k2.c, TT(a61) * k1.c)))), z.c)
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
@@ -517,11 +755,20 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         ex = PM_FMA(TT(e6), gx, ex); ey = PM_FMA(TT(e6), gy, ey);
 #define S72(c) (has2 ? PM_FMA(TT(a72), k2.c, TT(a71) * k1.c) : TT(a71) * k1.c)
 #define ST7(c) PM_FMA(h, PM_FMA(TT(a76), k6.c, PM_FMA(TT(a75), k5.c, PM_FMA(TT(a74), k4.c, PM_FMA(TT(a73), k3.c, S72(c))))), z.c)
-        Vec5 un;
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax * ipx, z.x); un.y = PM_FMA(h, ay * ipy, z.y);
         rhs3<FAST, METRIC, DB>(P, un.lne, un.cx, un.cy, W, k7, pc);
         st.rhs += 6;
+        if (AUTO) {   /* Tsit5 inside the composite: eigen_est = ||k7 - k6|| / ||u - g6||, RMS over the 5 components */
+            const double g6x = PM_FMA(h, s6x * ipx, z.x), g6y = PM_FMA(h, s6y * ipy, z.y);
+            double a, b, nu = 0.0, nd = 0.0;
+            a = k7.lne - k6.lne; b = un.lne - gl; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
+            a = k7.cx - k6.cx; b = un.cx - gx; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
+            a = k7.cy - k6.cy; b = un.cy - gy; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
+            a = un.cx * ipx - gx * ipx; b = un.x - g6x; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
+            a = un.cy * ipy - gy * ipy; b = un.y - g6y; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
+            eig = __builtin_sqrt(nu / nd);
+        }
         ex = PM_FMA(TT(e7), un.cx, ex) * ipx; ey = PM_FMA(TT(e7), un.cy, ey) * ipy;
 #define E12(c) (has2 ? PM_FMA(TT(e2), k2.c, TT(e1) * k1.c) : TT(e1) * k1.c)
 #define ERRN(c) (h * PM_FMA(TT(e7), k7.c, PM_FMA(TT(e6), k6.c, PM_FMA(TT(e5), k5.c, PM_FMA(TT(e4), k4.c, PM_FMA(TT(e3), k3.c, E12(c)))))))
@@ -529,7 +776,6 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         /* EEst² = (1/5) Σ (e_i/s_i)² with ONE reciprocal (kernel order): every numerator is
          * multiplied by the other four scales, the sum is divided by (Π s_i)².  The controller
          * works on ln EEst = ½ ln EEst², so no square root is taken either. */
-        double EE2;
         {
             double s0 = ERRS(z.lne, un.lne), s1 = ERRS(z.cx, un.cx), s2 = ERRS(z.cy, un.cy);
             double s3 = ERRS(z.x, un.x), s4 = ERRS(z.y, un.y);
@@ -554,6 +800,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #undef ERRS
 #undef S72
 #undef E12
+        }   /* explicit pair */
+        if (AUTO) { have_eig = true; if (!(eig == eig)) eig = 0.0; }
         if (!(EE2 == EE2)) { EE2 = pm_inf(); st.status |= 128 /*PICLES_ST_NONFINITE*/; }
         /* PI controller in log space (kernel order): 1/q = γ·qold^β2 / EEst^β1, clamped to
          * [qmin, qmax]; lq = ln(qold) is the carried controller memory. One log + one exp per step. */
@@ -578,6 +826,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         }
     }
     dtn = dt;
+    if (AUTO) *asw = (int)((unsigned int)as_count << 1) | (as_stiff ? 1 : 0);
 }
 
 #endif /* PICLES_PHYSICS_H */

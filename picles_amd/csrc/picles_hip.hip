@@ -66,6 +66,7 @@ struct Arrays {
     double *state, *movie;   /* 3 planes */
     double *z;               /* 5 planes */
     double *qold, *dtn;
+    int *asw;                /* solver 2: AutoSwitch state (counter << 1 | rosenbrock_active; ASW_FRESH after a reinit!) */
     unsigned char *on, *pflags;
     int *status;
     double *u0, *v0, *u1, *v1;
@@ -175,6 +176,7 @@ __global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, cons
     A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
     A.on[t] = (unsigned char)on;
     A.qold[t] = PI_LNQOLDINIT;
+    A.asw[t] = ASW_FRESH;
     A.dtn[t] = P.dt0;
     A.status[t] = 0;
     A.state[t] = e; A.state[t + A.n] = mx; A.state[t + 2 * A.n] = my;
@@ -192,15 +194,15 @@ struct StepStats {
     int reach;
 };
 
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false, bool AUTO = false>
 __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
                                                 double &dtn, double t_start, double DT, StepStats &S,
-                                                double m11 = 0.0, double m22 = 0.0, double pc = 0.0)
+                                                double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
 {
     int status = PICLES_ST_STEPPED;
     if (on) {
         S.adv = 1;
-        integrate_dp5<FAST, STATIC, METRIC, TSIT, DB>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc);
+        integrate_dp5<FAST, STATIC, METRIC, TSIT, DB, AUTO>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc, asw);
         status |= S.st.status;
     } else {
         double u, v;
@@ -321,7 +323,7 @@ __device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r
  * adaptive RK loop runs in registers.  Writes the particle's scatter record instead of
  * scattering: the scatter itself is k_scatter / k_step / k_push_tiles.
  * ---------------------------------------------------------------------------------------- */
-template <bool FAST, bool STATIC, bool METRIC, bool TSIT>
+template <bool FAST, bool STATIC, bool METRIC, bool TSIT, bool AUTO>
 __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
                                                    int r0, int n0, int r1, int n1)
 {
@@ -340,8 +342,10 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         double qold = A.qold[t], dtn = A.dtn[t];
         Wind w = load_wind(P, A, t);
         int status;
-        if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t]);
-        else status = advance_particle<FAST, STATIC, false, TSIT>(P, w, z, on, qold, dtn, t_start, DT, S);
+        int asw = AUTO ? A.asw[t] : 0;
+        if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, false, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
+        else status = advance_particle<FAST, STATIC, false, TSIT, false, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
+        if (AUTO) A.asw[t] = asw;
         A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
         A.on[t] = (unsigned char)on;
         A.qold[t] = qold;
@@ -397,7 +401,7 @@ __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &
     int br = remesh_regs(P, w, pf, e, mx, my, clock, DT, z);
     if (br <= 1) {
         A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
-        if (br == 1) { A.qold[t] = PI_LNQOLDINIT; reseeds = 1; }   /* reinit! */
+        if (br == 1) { A.qold[t] = PI_LNQOLDINIT; A.asw[t] = ASW_FRESH; reseeds = 1; }   /* reinit! */
         A.dtn[t] = -1.0;
         A.on[t] = 1;
     } else {
@@ -979,7 +983,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     *out = nullptr;
     if (g->Nx < 2 || g->Ny < 2) { g_create_error = "grid must be at least 2x2"; return -2; }
     if (g->j_begin < 0 || g->j_end > g->Ny || g->j_end <= g->j_begin) { g_create_error = "bad slab rows [j_begin,j_end)"; return -2; }
-    if (o->solver != 0 && o->solver != 1) { g_create_error = "solver must be 0 (DP5) or 1 (Tsit5)"; return -3; }
+    if (o->solver < 0 || o->solver > 2) { g_create_error = "solver must be 0 (DP5), 1 (Tsit5) or 2 (AutoTsit5(Rosenbrock23()))"; return -3; }
     if (halo_rows < 1) halo_rows = 1;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1080,7 +1084,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     A.n = n;
     CK(hipMalloc(&A.state, 3 * n * 8)); CK(hipMalloc(&A.movie, 3 * n * 8));
     CK(hipMalloc(&A.z, 5 * n * 8));
-    CK(hipMalloc(&A.qold, n * 8)); CK(hipMalloc(&A.dtn, n * 8));
+    CK(hipMalloc(&A.qold, n * 8)); CK(hipMalloc(&A.dtn, n * 8)); CK(hipMalloc(&A.asw, n * 4)); CK(hipMemset(A.asw, 0, n * 4));
     CK(hipMalloc(&A.on, n)); CK(hipMalloc(&A.pflags, n)); CK(hipMalloc(&A.status, n * 4));
     CK(hipMalloc(&A.u0, n * 8)); CK(hipMalloc(&A.v0, n * 8)); CK(hipMalloc(&A.u1, n * 8)); CK(hipMalloc(&A.v1, n * 8));
     CK(hipMalloc(&A.cnt, NSLOTS * sizeof(DevCounters)));
@@ -1109,7 +1113,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     Arrays &A = c->A;
-    hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.on);
+    hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.asw); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
     hipFree(A.cnt); hipFree(c->d_mask);
@@ -1356,8 +1360,9 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
         bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
         dim3 grid(nblocks(nt, 256)), block(256);
         Arrays A = arrays_for(c, c->cur, c->cur);
-#define LAUNCH_ADV2(F, S, M) do { if (P.solver) hipLaunchKernelGGL((k_advance<F, S, M, true>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); \
-                                   else hipLaunchKernelGGL((k_advance<F, S, M, false>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); } while (0)
+#define LAUNCH_ADV2(F, S, M) do { if (P.solver == 2) hipLaunchKernelGGL((k_advance<F, S, M, true, true>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); \
+                                   else if (P.solver) hipLaunchKernelGGL((k_advance<F, S, M, true, false>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); \
+                                   else hipLaunchKernelGGL((k_advance<F, S, M, false, false>), grid, block, 0, s, c->P, c->G, A, c->clock, c->step_dt, r0, n0, r1, n1); } while (0)
 #define LAUNCH_ADV(F, S, M) LAUNCH_ADV2(F, S, M)
         if (c->A.pc) LAUNCH_ADV(false, false, true);   /* per-node metric: the general code path */
         else if (fast && P.wind_static) LAUNCH_ADV(true, true, false);
@@ -1381,6 +1386,7 @@ static bool step_fusable(const picles_ctx *c, int flags)
 {
     if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps) return false;
     const KParams &P = c->P;
+    if (P.solver == 2) return false;   /* the auto-switching solver runs as k_advance + k_scatter */
     const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
     /* the time-varying-wind and per-node-metric flavours of the fused kernel exist for the specialised physics */
     if (c->wind_grid_on) return fast;

@@ -51,9 +51,10 @@ def build_structs(grid: TwoDCartesianGridMesh, ODEsys: ParticleSystem2D, ODEsets
     p.dir_deadband = float(getattr(ODEsys, "dir_deadband", 0.0))
     o = K.PiclesOde()
     solver = str(ODEsets.solver).replace(" ", "").rstrip("()") if not isinstance(ODEsets.solver, int) else ODEsets.solver
-    solver_id = {"DP5": 0, 0: 0, "Tsit5": 1, 1: 1, "AutoTsit5(Rosenbrock23": 1, "AutoTsit5(Rosenbrock23())": 1}.get(solver)
+    solver_id = {"DP5": 0, 0: 0, "Tsit5": 1, 1: 1, "AutoTsit5(Rosenbrock23": 2, "AutoTsit5(Rosenbrock23())": 2,
+                 "AutoTsit5": 2, 2: 2}.get(solver)
     if solver_id is None:
-        raise NotImplementedError(f"solver {ODEsets.solver!r}: the kernels implement DP5 and Tsit5 (DESIGN.md §2)")
+        raise NotImplementedError(f"solver {ODEsets.solver!r}: the kernels implement DP5, Tsit5 and AutoTsit5(Rosenbrock23()) (DESIGN.md §2)")
     if not ODEsets.adaptive:
         raise NotImplementedError("adaptive=false is not implemented")
     o.abstol, o.reltol, o.dt0, o.dtmin = ODEsets.abstol, ODEsets.reltol, ODEsets.dt, ODEsets.dtmin

@@ -59,6 +59,8 @@ def lib(kind: str = "libm") -> C.CDLL:
         "picles_oracle_charge_to_particle": (None, [DP, DP]),
         "picles_oracle_index_weight": (None, [D, C.c_int32, C.POINTER(C.c_int64), DP]),
         "picles_oracle_integrate": (C.c_int32, [VP, C.c_int64, DP, DP, DP, D, D, C.POINTER(C.c_uint64)]),
+        "picles_oracle_integrate_auto": (C.c_int32, [VP, C.c_int64, DP, DP, DP, C.POINTER(C.c_int32), D, D, C.POINTER(C.c_uint64)]),
+        "picles_oracle_rhs_jvp": (None, [VP, DP, D, D, DP, DP, DP]),
         "picles_oracle_is_pmath": (C.c_int32, []),
         "picles_oracle_has_openmp": (C.c_int32, []),
         "picles_oracle_math": (None, [C.c_int32, C.c_int64, DP, DP, DP]),
@@ -276,3 +278,25 @@ class OracleModel:
         stats = (C.c_uint64 * 3)()
         st = self.L.picles_oracle_integrate(self.h, idx, K.dptr(z), K.dptr(q), K.dptr(d), t_start, DT, stats)
         return z, dict(rhs=stats[0], acc=stats[1], rej=stats[2], status=st, qold=q[0], dt=d[0])
+
+
+def _add_auto_methods():
+    def rhs_jvp(self, z, u, v, seed):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        sd = np.ascontiguousarray(seed, dtype=np.float64)
+        f, df = np.zeros(3), np.zeros(3)
+        self.L.picles_oracle_rhs_jvp(self.h, K.dptr(z), u, v, K.dptr(sd), K.dptr(f), K.dptr(df))
+        return f, df
+
+    def integrate_auto(self, idx, z, t_start, DT, qold=-9.210340371976182, dtn=-1.0, asw=-2**31):
+        z = np.array(z, dtype=np.float64)
+        q, d = np.array([qold]), np.array([dtn])
+        a = C.c_int32(asw)
+        stats = (C.c_uint64 * 3)()
+        st = self.L.picles_oracle_integrate_auto(self.h, idx, K.dptr(z), K.dptr(q), K.dptr(d), C.byref(a), t_start, DT, stats)
+        return z, dict(rhs=stats[0], acc=stats[1], rej=stats[2], status=st, qold=q[0], dt=d[0], asw=a.value)
+    OracleModel.rhs_jvp = rhs_jvp
+    OracleModel.integrate_auto = integrate_auto
+
+
+_add_auto_methods()

@@ -61,8 +61,12 @@ def test_sphere_unobserved_run_is_fused_and_bitwise():
     from picles_amd.simulations import Simulation, initialize_simulation
     from picles_amd.timesteppers import time_step
     from helpers import make_model
-    cfg = configs.sphere_aqua(n_steps=8)
-    g, o = make_model(configs.sphere_aqua(n_steps=8), "hip"), make_model(configs.sphere_aqua(n_steps=8), ("pmath", 1))
+    def mk():
+        c = configs.sphere_aqua(n_steps=8)
+        c.model["ODEsets"].solver = "Tsit5"        # the explicit pairs run fused; the default (auto-switching) solver does not
+        return c
+    cfg = mk()
+    g, o = make_model(mk(), "hip"), make_model(mk(), ("pmath", 1))
     for m in (g, o):
         initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
     g.backend.enable_timing(True)
