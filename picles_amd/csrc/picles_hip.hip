@@ -604,8 +604,8 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * ---------------------------------------------------------------------------------------- */
 /* STATIC = false: winds linear in time over the step window (u0,v0 -> u1,v1); the remesh of the previous step
  * needs the wind at ITS start-of-step clock = level 0 of the previous window, kept in (uP, vP) */
-template <bool FAST, bool TSIT, bool DB, bool STATIC, bool METRIC>
-__global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
+template <bool FAST, bool TSIT, bool DB, bool STATIC, bool METRIC, bool AUTO>
+__global__ void __launch_bounds__(256, (FAST && !AUTO) ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
     dp_device_init(TSIT ? 1 : 0);
@@ -627,12 +627,14 @@ __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, 
             double qold = A.qold[t], dtn = -1.0;
             int br = remesh_regs_lazy(P, pf, s0, s1, s2, DT_prev, z, STATIC ? &A.u0[t] : &A.uP[t], STATIC ? &A.v0[t] : &A.vP[t]);
             int on = (br <= 1);
-            if (br == 1) { qold = PI_LNQOLDINIT; S.reseeds = 1; }
+            int asw = AUTO ? A.asw[t] : 0;
+            if (br == 1) { qold = PI_LNQOLDINIT; asw = ASW_FRESH; S.reseeds = 1; }
             unsigned int rs = S.reseeds;
             S.reseeds = 0;
             int status;
-            if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t]);
-            else status = advance_particle<FAST, STATIC, false, TSIT, DB>(P, w, z, on, qold, dtn, t_start, DT, S);
+            if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, DB, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
+            else status = advance_particle<FAST, STATIC, false, TSIT, DB, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
+            if (AUTO) A.asw[t] = asw;
             S.reseeds += rs;
             A.qold[t] = qold;
             A.status[t] = status;
@@ -1386,11 +1388,11 @@ static bool step_fusable(const picles_ctx *c, int flags)
 {
     if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps) return false;
     const KParams &P = c->P;
-    if (P.solver == 2) return false;   /* the auto-switching solver runs as k_advance + k_scatter */
     const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
     /* the time-varying-wind and per-node-metric flavours of the fused kernel exist for the specialised physics */
     if (c->wind_grid_on) return fast;
     if (c->A.pc) return fast && P.wind_static != 0;
+    if (P.solver == 2) return fast && P.wind_static != 0;   /* the auto-switching flavour exists for the specialised physics */
     return P.wind_static != 0;
 }
 
@@ -1412,8 +1414,18 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     bool db = P.deadband2 > 0.0;
     dim3 grid(nblocks(nt, 256)), block(256);
     timing_begin(c, s, 0);
-#define LAUNCH_STEP(F, T, D, S, M) hipLaunchKernelGGL((k_step<F, T, D, S, M>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
-    if (fast) {     /* specialised physics: solver x dead band x static winds x per-node metric */
+#define LAUNCH_STEP(F, T, D, S, M) LAUNCH_STEP6(F, T, D, S, M, false)
+#define LAUNCH_STEP6(F, T, D, S, M, AU) hipLaunchKernelGGL((k_step<F, T, D, S, M, AU>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
+    if (fast && P.solver == 2) {   /* auto-switching solver: dead band x static winds x per-node metric */
+        const int key = (db ? 4 : 0) | (P.wind_static ? 2 : 0) | (c->A.pc ? 1 : 0);
+        switch (key) {
+#define CASE_AUTO(k, D, S, M) case k: LAUNCH_STEP6(true, true, D, S, M, true); break;
+            CASE_AUTO(0, false, false, false) CASE_AUTO(1, false, false, true) CASE_AUTO(2, false, true, false) CASE_AUTO(3, false, true, true)
+            CASE_AUTO(4, true, false, false)  CASE_AUTO(5, true, false, true)  CASE_AUTO(6, true, true, false)  CASE_AUTO(7, true, true, true)
+#undef CASE_AUTO
+        }
+    }
+    else if (fast) {     /* specialised physics: solver x dead band x static winds x per-node metric */
         const int key = (P.solver ? 8 : 0) | (db ? 4 : 0) | (P.wind_static ? 2 : 0) | (c->A.pc ? 1 : 0);
         switch (key) {
 #define CASE_STEP(k, T, D, S, M) case k: LAUNCH_STEP(true, T, D, S, M); break;
@@ -1431,6 +1443,7 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     else if (P.solver) LAUNCH_STEP(false, true, false, true, false);      /* general physics: static winds, Cartesian (step_fusable) */
     else LAUNCH_STEP(false, false, false, true, false);
 #undef LAUNCH_STEP
+#undef LAUNCH_STEP6
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
     return 0;
