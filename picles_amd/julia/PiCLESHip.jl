@@ -11,6 +11,7 @@
 module PiCLESHip
 
 using PiCLES
+using DifferentialEquations: DP5, Tsit5
 using PiCLES.Architectures: Abstract2DModel
 using PiCLES.Grids.CartesianGrid: TwoDCartesianGridMesh
 using PiCLES.custom_structures: N_Periodic
@@ -96,7 +97,8 @@ function WaveGrowth2DHIP(; grid::TwoDCartesianGridMesh, winds, ODEsets, γ, q, I
     p = Ref(picles_phys(P.r_g, P.C_α, P.C_φ, P.C_e, P.g, γ, q,
                         IDConstants.c_β, IDConstants.c_D, IDConstants.c_e, IDConstants.c_alpha,
                         propagation, input, dissipation, peak_shift, direction, 0, 0.0))
-    o = Ref(picles_ode(ODEsets.abstol, ODEsets.reltol, ODEsets.dt, ODEsets.dtmin, ODEsets.force_dtmin, 0,
+    solver_id = ODEsets.solver isa DP5 ? 0 : ODEsets.solver isa Tsit5 ? 1 : 2     # 2 = AutoTsit5(Rosenbrock23()), the default
+    o = Ref(picles_ode(ODEsets.abstol, ODEsets.reltol, ODEsets.dt, ODEsets.dtmin, ODEsets.force_dtmin, solver_id,
                        ODEsets.maxiters, ODEsets.log_energy_minimum, ODEsets.log_energy_maximum,
                        ODEsets.wind_min_squared, ODEsets.timestep))
     fixed = !(ODEinit_type isa String)
