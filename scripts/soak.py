@@ -5,7 +5,14 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from picles_amd import configs, _capi as K
 from picles_amd.parallel import SlabModel
-cfg = configs.box4096(n=2048)
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--solver", default="DP5")
+ap.add_argument("--winds", type=lambda s: tuple(float(x) for x in s.split(",")), default=(10.0, 10.0))
+ap.add_argument("--grid-n", dest="n", type=int, default=2048)
+args = ap.parse_args()
+cfg = configs.box4096(n=args.n, U10=args.winds[0], V10=args.winds[1])
+cfg.model["ODEsets"].solver = args.solver
 m = SlabModel(cfg.model, 0, 1)
 m.seed()
 t0 = time.perf_counter()
