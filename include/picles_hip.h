@@ -37,7 +37,8 @@ typedef struct picles_grid {
     int32_t Nx, Ny;          /* global node counts                                   */
     double  dx, dy;          /* node spacing [m]; ProjetionKernel M = diag(1/dx,1/dy) */
     int32_t periodic_x;      /* 1: Nx isa N_Periodic, 0: N_NonPeriodic (scatter wrap/drop) */
-    int32_t periodic_y;
+    int32_t periodic_y;      /* 0 / 1 likewise; 2: Ny isa N_TripolarNorth — open at the south edge, corners beyond the
+                                north edge fold back mirrored in x (ParticleInCell.jl:353-361, 409-428); needs periodic_x */
     const int8_t *mask;      /* Nx*Ny total mask {0 land,1 ocean,2 land bnd,3 grid bnd};
                                 NULL => all ocean + make_boundaries() ring on non-periodic axes */
     int32_t j_begin, j_end;  /* rows owned by this context (slab); 0, Ny for one device */

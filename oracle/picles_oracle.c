@@ -1122,8 +1122,17 @@ static int po_particle_to_node(po_model *M, int32_t i, int32_t j, const double z
     static const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 0, 1, 1}; /* construct_loop order */
     for (int k = 0; k < 4; k++) {
         int64_t ii = xi[ox[k]], jj = yi[oy[k]];
+        if (M->g.periodic_y == 2) {
+            /* N_TripolarNorth (ParticleInCell.jl:353-361, TripolarNorthBoundary :409-428), 0-based: below the south
+             * edge the corner is dropped; above the north fold it lands mirrored in x on row 2Ny-1-jj, charge unchanged */
+            if (jj < 0) continue;
+            if (jj >= M->Ny) {
+                ii = M->Nx - 1 - po_wrap(ii + 1, M->Nx);
+                jj = 2 * (int64_t)M->Ny - 1 - jj;
+                if (jj < 0) continue;
+            }
+        } else if (!M->g.periodic_y && !(jj >= 0 && jj < M->Ny)) continue;
         if (!M->g.periodic_x && !(ii >= 0 && ii < M->Nx)) continue;
-        if (!M->g.periodic_y && !(jj >= 0 && jj < M->Ny)) continue;
         ii = po_wrap(ii, M->Nx);
         jj = po_wrap(jj, M->Ny);
         double w = xw[ox[k]] * yw[oy[k]];
@@ -1418,6 +1427,20 @@ PO_EXPORT int32_t picles_oracle_advance(po_model *M, double DT)
     return 0;
 }
 
+/* ParticleToNode! alone, for the particles as they are (test hook for the boundary rules of the push) */
+PO_EXPORT int32_t picles_oracle_scatter_only(po_model *M)
+{
+    if (!M->single_slab) return -5;
+    for (int64_t s = 0; s < M->n_step; s++) {
+        int64_t idx = M->steplist[s];
+        if (!M->on[idx]) continue;
+        double z[5];
+        for (int c = 0; c < 5; c++) z[c] = M->z[idx + c * M->N];
+        po_particle_to_node(M, (int32_t)(idx % M->Nx), (int32_t)(idx / M->Nx), z);
+    }
+    return 0;
+}
+
 /* time_step!_remesh (TimeSteppers.jl:182-193) */
 PO_EXPORT int32_t picles_oracle_remesh(po_model *M, double DT)
 {
@@ -1602,9 +1625,38 @@ static void po_pull_node(po_model *M, int i, int jl, int R, int accum, double s[
     s[0] = accum ? M->state[t] : 0.0;
     s[1] = accum ? M->state[t + M->N] : 0.0;
     s[2] = accum ? M->state[t + 2 * M->N] : 0.0;
+    if (M->g.periodic_y == 2 && j >= Ny - R) {
+        /* tripolar north fold: a node of the top band receives ordinary corners and corners folded back over the
+         * seam (mirrored in x).  Sources are visited in ascending index; each replays its four corners in
+         * construct_loop order through the boundary rule of the push. */
+        static const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 0, 1, 1};
+        for (int grp = 1; grp <= M->ngroups; grp++)
+            for (int js = (j - R > 0 ? j - R : 0); js < Ny; js++) {
+                const double *rr = po_rec_row(M, js - M->j0 + M->R);
+                for (int is = 0; is < Nx; is++) {
+                    if (rr[5 * Nx + is] != (double)grp) continue;
+                    int64_t xi[2], yi[2];
+                    double xw[2], yw[2];
+                    po_index_weight(rr[3 * Nx + is], is, xi, xw);
+                    po_index_weight(rr[4 * Nx + is], js, yi, yw);
+                    for (int k = 0; k < 4; k++) {
+                        int64_t ii = xi[ox[k]], jj = yi[oy[k]];
+                        if (jj < 0) continue;
+                        if (jj >= Ny) { ii = Nx - 1 - po_wrap(ii + 1, Nx); jj = 2 * (int64_t)Ny - 1 - jj; }
+                        else ii = po_wrap(ii, Nx);
+                        if (ii != i || jj != j) continue;
+                        double w = xw[ox[k]] * yw[oy[k]];
+                        s[0] += w * rr[is];
+                        s[1] += w * rr[Nx + is];
+                        s[2] += w * rr[2 * Nx + is];
+                    }
+                }
+            }
+        return;
+    }
     int dxs[W], sxs[W], dys[W], sys[W];
     int nxc = po_axis_candidates(i, Nx, R, M->g.periodic_x, dxs, sxs);
-    int nyc = po_axis_candidates(j, Ny, R, M->g.periodic_y, dys, sys);
+    int nyc = po_axis_candidates(j, Ny, R, M->g.periodic_y == 1, dys, sys);
     for (int grp = 1; grp <= M->ngroups; grp++)
         for (int a = 0; a < nyc; a++) {
             int dj = dys[a];

@@ -46,6 +46,7 @@
 struct GridP {
     int Nx, Ny;            /* global */
     int periodic_x, periodic_y;
+    int tripolar;          /* N_TripolarNorth: y is not periodic; corners beyond the north edge fold back, mirrored in x */
     int j_begin, ny_loc;
     int R;                 /* ghost record rows per side (halo blocks); row offset of the records */
     int Rp;                /* reach of the pull scatter: >0 fixed (slabs: = R), 0 = read the
@@ -547,13 +548,71 @@ __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i
     }
 }
 
+/* floor modulo for b > 0 */
+__device__ __forceinline__ int floor_mod(int a, int b) { int r = a % b; return (r < 0) ? r + b : r; }
+
+/* N_TripolarNorth (ParticleInCell.jl:353-361, TripolarNorthBoundary :409-428): a node of the top band (j >= Ny - R)
+ * receives ordinary corners and corners folded back over the north seam, mirrored in x.  Candidate sources — rows
+ * j-R .. Ny-1, columns within R of i or of the mirror column Nx-2-i — are visited in ascending index; each replays
+ * its four corners in construct_loop order through the boundary rule of the push (0-based): corner (ci, cj) with
+ * cj >= Ny lands on (Nx-1 - mod(ci+1, Nx), 2Ny-1-cj), with cj < 0 is dropped, otherwise on (mod(ci, Nx), cj). */
+__device__ __forceinline__ void pull_node_tripolar(const GridP &G, const Arrays &A, int i, int jl, int R,
+                                                   double &s0, double &s1, double &s2)
+{
+    const int RO = G.R, Nx = G.Nx, Ny = G.Ny, j = jl + G.j_begin, W = 2 * R + 1;
+    const double *__restrict__ rec = A.rec;
+    const unsigned int pl = (unsigned int)Nx, rowlen = 6u * pl;
+    const int cB = floor_mod(Nx - 2 - i, Nx);
+    const bool narrow = (2 * W <= Nx);       /* two disjoint-or-touching windows; otherwise scan the whole row */
+    const int a0 = floor_mod(i - R, Nx), b0 = floor_mod(cB - R, Nx);
+    for (int grp = 1; grp <= G.ngroups; grp++) {
+        for (int js = max(0, j - R); js < Ny; js++) {
+            const unsigned int rbase = (unsigned int)(js - G.j_begin + RO) * rowlen;
+            /* ascending merge of the two wrapped windows [a0, a0+W) and [b0, b0+W) (mod Nx) */
+            int ka = 0, kb = 0, is_full = 0;
+            while (narrow ? (ka < W || kb < W) : (is_full < Nx)) {
+                int is;
+                if (narrow) {
+                    /* element k of a wrapped window in ascending order: the wrapped-around part comes first */
+                    const int wa = a0 + W - Nx, wb = b0 + W - Nx;      /* > 0: that many elements wrap to 0.. */
+                    int ea = (ka < W) ? ((wa > 0) ? ((ka < wa) ? ka : a0 + (ka - wa)) : a0 + ka) : 0x7fffffff;
+                    int eb = (kb < W) ? ((wb > 0) ? ((kb < wb) ? kb : b0 + (kb - wb)) : b0 + kb) : 0x7fffffff;
+                    is = min(ea, eb);
+                    if (ea == is) ka++;
+                    if (eb == is) kb++;
+                } else {
+                    is = is_full++;
+                }
+                const int ci0 = (int)rec[rbase + 5u * pl + (unsigned int)is];
+                if (ci0 == 0 || (ci0 & 3) != grp) continue;
+                const int bx = ((ci0 >> 2) & 4095) - REC_BIAS, by = (ci0 >> 14) - REC_BIAS;
+                const double wxh = rec[rbase + 3u * pl + (unsigned int)is], wyh = rec[rbase + 4u * pl + (unsigned int)is];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int ax = k & 1, ay = k >> 1;
+                    int ci = is + bx + ax, cj = js + by + ay;
+                    if (cj < 0) continue;
+                    if (cj >= Ny) { ci = Nx - 1 - floor_mod(ci + 1, Nx); cj = 2 * Ny - 1 - cj; }
+                    else ci = floor_mod(ci, Nx);
+                    if (ci != i || cj != j) continue;
+                    const double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
+                    s0 += w * rec[rbase + (unsigned int)is];
+                    s1 += w * rec[rbase + pl + (unsigned int)is];
+                    s2 += w * rec[rbase + 2u * pl + (unsigned int)is];
+                }
+            }
+        }
+    }
+}
+
 /* reach dispatch: compile-time reach 1 and 2, runtime reach otherwise; a reach that wraps around a periodic
  * axis takes the general (aliasing-aware) form */
 __device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i, int jl, int R,
                                          double &s0, double &s1, double &s2)
 {
     const int W = 2 * R + 1;
-    if ((G.periodic_x && W > G.Nx) || (G.periodic_y && W > G.Ny)) pull_node_aliased(G, A, i, jl, R, s0, s1, s2);
+    if (G.tripolar && jl + G.j_begin >= G.Ny - R) pull_node_tripolar(G, A, i, jl, R, s0, s1, s2);
+    else if ((G.periodic_x && W > G.Nx) || (G.periodic_y && W > G.Ny)) pull_node_aliased(G, A, i, jl, R, s0, s1, s2);
     else if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
     else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
     else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
@@ -1029,7 +1088,13 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.wind_static = 1; P.tw0 = 0.0; P.inv_dtw = 0.0;
 
     GridP &G = c->G;
-    G.Nx = g->Nx; G.Ny = g->Ny; G.periodic_x = g->periodic_x; G.periodic_y = g->periodic_y;
+    G.Nx = g->Nx; G.Ny = g->Ny; G.periodic_x = (g->periodic_x != 0); G.periodic_y = (g->periodic_y == 1);
+    G.tripolar = (g->periodic_y == 2);
+    if (g->periodic_y < 0 || g->periodic_y > 2 || (G.tripolar && !G.periodic_x)) {
+        g_create_error = "periodic_y must be 0, 1 or 2 (tripolar north, which needs a periodic x axis)";
+        delete c;
+        return -2;
+    }
     G.j_begin = g->j_begin; G.ny_loc = g->j_end - g->j_begin;
     G.single_slab = (g->j_begin == 0 && g->j_end == g->Ny);
     G.R = halo_rows;
@@ -1527,6 +1592,7 @@ static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh)
     int accum = (zero_first || c->state_zero) ? 0 : 1;
     if (flags & PICLES_STEP_ATOMIC) {
         if (!c->G.single_slab) return fail(c, -5, "PICLES_STEP_ATOMIC is single-slab only");
+        if (c->G.tripolar) return fail(c, -5, "PICLES_STEP_ATOMIC does not implement the tripolar fold: use the deterministic pull");
         if (!accum) HIPCHK(c, hipMemsetAsync(c->A.state, 0, 3 * c->A.n * 8, s));
         int ntx = (c->G.Nx + PT_TX - 1) / PT_TX, nty = (c->G.ny_loc + PT_TY - 1) / PT_TY;
         timing_begin(c, s, 1);
@@ -1835,6 +1901,7 @@ PX_EXPORT int32_t picles_scatter_particles(picles_ctx *c, int64_t np, const int3
 {
     if (!c || np < 0 || (np > 0 && (!ij || !xy || !charge))) return -1;
     if (!c->G.single_slab) return fail(c, -5, "picles_scatter_particles is single-slab only");
+    if (c->G.tripolar) return fail(c, -5, "picles_scatter_particles does not implement the tripolar fold");
     if (np == 0) return 0;
     if (np > 0x7fffffffLL) return fail(c, -2, "too many particles for one call");
     HIPCHK(c, hipSetDevice(c->device));

@@ -25,6 +25,25 @@ class N_NonPeriodic:
         return self.N
 
 
+@dataclass(frozen=True)
+class N_TripolarNorth:
+    """custom_structures.jl:59: the y axis of a tripolar grid — open at the south edge, folded onto itself (mirrored in x)
+    at the north edge (ParticleInCell.jl:353-361, 409-428).  The reference builds it only in TripolarGridMOM6.jl, whose
+    MOM6 file reader is out of scope; here any regular mesh can carry it (periodic_boundary = (True, "tripolar_north"))."""
+    N: int
+
+    def __int__(self):
+        return self.N
+
+
+def _axis_type(flag, N):
+    if isinstance(flag, str):
+        if flag != "tripolar_north":
+            raise ValueError(f"unknown boundary type {flag!r}")
+        return N_TripolarNorth(N)
+    return N_Periodic(N) if flag else N_NonPeriodic(N)
+
+
 def interior_boundary(mask: np.ndarray) -> np.ndarray:
     """mask_utils.jl:14-22: land points adjacent (4-neighbourhood, circular) to ocean"""
     mask = mask.astype(bool)
@@ -74,8 +93,8 @@ class TwoDCartesianGridStatistics:
         self.dx, self.dy = self.dimx / self.Ndx, self.dimy / self.Ndy
         self.area = self.dx * self.dy
         self.xmin, self.xmax, self.ymin, self.ymax = xmin, xmax, ymin, ymax
-        self.Nx = N_Periodic(Nx) if periodic_boundary[0] else N_NonPeriodic(Nx)
-        self.Ny = N_Periodic(Ny) if periodic_boundary[1] else N_NonPeriodic(Ny)
+        self.Nx = _axis_type(periodic_boundary[0], Nx)
+        self.Ny = _axis_type(periodic_boundary[1], Ny)
         self.angle_dx = angle
 
 
@@ -147,8 +166,8 @@ class TwoDSphericalGridStatistics:
     def __init__(self, xmin, xmax, Nx: int, ymin, ymax, Ny: int, mask_value=1, angle=0.0, periodic_boundary=(False, False)):
         self.dimx, self.dimy = xmax - xmin, ymax - ymin
         self.Ndx, self.Ndy = Nx - 1, Ny - 1
-        self.Nx = N_Periodic(Nx) if periodic_boundary[0] else N_NonPeriodic(Nx)
-        self.Ny = N_Periodic(Ny) if periodic_boundary[1] else N_NonPeriodic(Ny)
+        self.Nx = _axis_type(periodic_boundary[0], Nx)
+        self.Ny = _axis_type(periodic_boundary[1], Ny)
         self.dx_deg, self.dy_deg = self.dimx / self.Ndx, self.dimy / self.Ndy
         self.xmin, self.xmax, self.ymin, self.ymax = xmin, xmax, ymin, ymax
         self.angle_dx, self.mask_value = angle, mask_value

@@ -92,7 +92,8 @@ function WaveGrowth2DHIP(; grid::TwoDCartesianGridMesh, winds, ODEsets, γ, q, I
     mask = Matrix{Int8}(grid.data.mask)
     ms = isnothing(minimal_state) ? PiCLES.FetchRelations.MinimalState(2, 2, ODEsets.timestep) : minimal_state
     P = ODEsets.Parameters
-    g = Ref(picles_grid(st.Nx.N, st.Ny.N, st.dx, st.dy, st.Nx isa N_Periodic, st.Ny isa N_Periodic,
+    per_y = st.Ny isa N_Periodic ? 1 : (nameof(typeof(st.Ny)) == :N_TripolarNorth ? 2 : 0)
+    g = Ref(picles_grid(st.Nx.N, st.Ny.N, st.dx, st.dy, st.Nx isa N_Periodic, per_y,
                         pointer(mask), 0, st.Ny.N))
     p = Ref(picles_phys(P.r_g, P.C_α, P.C_φ, P.C_e, P.g, γ, q,
                         IDConstants.c_β, IDConstants.c_D, IDConstants.c_e, IDConstants.c_alpha,

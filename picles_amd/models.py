@@ -38,7 +38,7 @@ def build_structs(grid: TwoDCartesianGridMesh, ODEsys: ParticleSystem2D, ODEsets
     g.Nx, g.Ny = int(st.Nx), int(st.Ny)
     g.dx, g.dy = st.dx, st.dy
     g.periodic_x = int(isinstance(st.Nx, N_Periodic))
-    g.periodic_y = int(isinstance(st.Ny, N_Periodic))
+    g.periodic_y = 2 if type(st.Ny).__name__ == "N_TripolarNorth" else int(isinstance(st.Ny, N_Periodic))
     g.j_begin, g.j_end = j_begin, (g.Ny if j_end is None else j_end)
     P = ODEsets.Parameters
     idc = ODEsys.IDConstants

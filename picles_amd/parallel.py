@@ -149,7 +149,7 @@ class SlabModel:
         self.j0, self.j1 = slab_rows(Ny, world, rank)
         g, p, o, m = build_structs(grid, ODEsys, ODEsets, defaults, self.minimal_state, self.periodic_boundary,
                                    j_begin=self.j0, j_end=self.j1)
-        self.periodic_y = bool(g.periodic_y)
+        self.periodic_y = (g.periodic_y == 1)      # 2 = tripolar north: no wrap link; the top slab folds locally
         if backend_factory is None:
             from .driver import HipModel
             self.backend = HipModel(g, p, o, m, mask=grid.data.mask, device=device, halo_rows=halo_rows)

@@ -40,6 +40,7 @@ def lib(kind: str = "libm") -> C.CDLL:
         "picles_oracle_advance": (C.c_int32, [VP, D]),
         "picles_oracle_remesh": (C.c_int32, [VP, D]),
         "picles_oracle_zero_state": (C.c_int32, [VP]),
+        "picles_oracle_scatter_only": (C.c_int32, [VP]),
         "picles_oracle_tick": (C.c_int32, [VP, D]),
         "picles_oracle_clock": (D, [VP]),
         "picles_oracle_time_step": (C.c_int32, [VP, D, C.c_int32]),
@@ -205,6 +206,9 @@ class OracleModel:
 
     def zero_state(self):
         self.L.picles_oracle_zero_state(self.h)
+
+    def scatter_only(self):
+        assert self.L.picles_oracle_scatter_only(self.h) == 0
 
     @property
     def clock(self):

