@@ -81,7 +81,10 @@ def scenario(seed):
                            desc=f"{nx}x{ny} per={per} tvar={tvar} calm={calm} {sets.solver} DT={DT} flavour={flavour} {sw}")
 
 
-@pytest.mark.parametrize("seed", range(96))
+N_SEEDS = int(__import__("os").environ.get("PICLES_FUZZ_SEEDS", "96"))      # raise for a longer hunt
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_scenario_bitwise(seed):
     g, o = make_model(scenario(seed), "hip"), make_model(scenario(seed), ORACLE)
     cfg = scenario(seed)
