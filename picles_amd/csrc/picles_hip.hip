@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
 /* STATIC = false: winds linear in time over the step window (u0,v0 -> u1,v1); the remesh of the previous step
  * needs the wind at ITS start-of-step clock = level 0 of the previous window, kept in (uP, vP) */
 template <bool FAST, bool TSIT, bool DB, bool STATIC, bool METRIC, bool AUTO>
-__global__ void __launch_bounds__(256, (FAST && !AUTO) ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
+__global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
     dp_device_init(TSIT ? 1 : 0);

@@ -11,6 +11,8 @@ export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 > $O/${R}_bench.json 2> $O/${R}_bench.err &&
 python bench.py --steps 10 --warmup 2 --no-cpu --winds 10,3 > $O/${R}_bench_generic.json 2>> $O/${R}_bench.err &&
 python bench.py --steps 10 --warmup 2 --no-cpu --winds 10,3 --deadband 1e-9 > $O/${R}_bench_generic_deadband.json 2>> $O/${R}_bench.err &&
+( python bench.py --steps 10 --warmup 2 --no-cpu --solver Tsit5 && python bench.py --steps 10 --warmup 2 --no-cpu --solver Tsit5 --winds 10,3 &&
+  python bench.py --steps 10 --warmup 2 --no-cpu --solver AutoTsit5 && python bench.py --steps 10 --warmup 2 --no-cpu --solver AutoTsit5 --winds 10,3 ) > $O/${R}_bench_solvers.jsonl 2>> $O/${R}_bench.err &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $O/${R}_stats.log 2>&1 &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_stats_generic -- python3 bench.py --steps 10 --warmup 2 --no-cpu --winds 10,3 > $O/${R}_stats_generic.log 2>&1 &&
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${R}_pmc_sq -- python3 bench.py --steps 6 --warmup 2 --no-cpu > $O/${R}_pmc_sq.log 2>&1 &&

@@ -17,6 +17,9 @@ shutil.copy(pick(f"{R}_stats", "kernel_stats.csv", "k_step"), out / f"{R}_bench_
 shutil.copy(pick(f"{R}_stats_generic", "kernel_stats.csv", "k_step"), out / f"{R}_bench_generic_kernel_stats.csv")
 shutil.copy(G / f"{R}_bench.json", out / f"{R}_bench.json")
 shutil.copy(G / f"{R}_bench_generic.json", out / f"{R}_bench_generic.json")
+for extra in (f"{R}_bench_generic_deadband.json", f"{R}_bench_solvers.jsonl", f"{R}_baseline_configs.jsonl"):
+    if (G / extra).exists():
+        shutil.copy(G / extra, out / extra)
 
 def agg(d):
     rows = list(csv.DictReader(open(pick(d, "counter_collection.csv", "k_step"))))
