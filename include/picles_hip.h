@@ -108,7 +108,8 @@ typedef struct picles_counters {
     uint64_t clamps;
     uint64_t maxiters_hits;
     uint64_t particles_advanced;  /* particles that ran the ODE       */
-    uint64_t halo_overflow;   /* particles that travelled beyond the scatter reach used */
+    uint64_t halo_overflow;   /* particles that travelled beyond the scatter reach the context covers — halo_rows for a
+                                 slab, 64 cells per model step for a whole-grid context — and were NOT scattered */
     int32_t  max_reach;       /* max |cell offset| any scatter corner had in the last advance */
     int32_t  _pad;
 } picles_counters;

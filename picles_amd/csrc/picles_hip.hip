@@ -129,6 +129,11 @@ __device__ __forceinline__ double *rec_row_out(const Arrays &A, const GridP &G, 
  * cell offsets (bx, by) = floor(x), floor(y) of the particle, packed into an exactly
  * representable integer-valued double (the planes stay one dtype => contiguous halo blocks) */
 #define REC_BIAS 2048
+/* A whole-grid context follows the scatter reach the advance measured, up to this many cells per model step; a
+ * particle that travels farther (not a sea state: 64 cells are > 100 km in 10 minutes on the reference's meshes) is
+ * not scattered and is counted in `halo_overflow`.  The pull visits (2R+1)² candidates per node: the cap also bounds
+ * the cost of a step poisoned by one runaway particle. */
+#define REACH_CAP 64
 __device__ __forceinline__ double rec_encode(int grp, int bx, int by)
 {
     return (double)(grp + 4 * (bx + REC_BIAS) + 4 * 4096 * (by + REC_BIAS));
@@ -245,7 +250,9 @@ __device__ __forceinline__ void write_record(const GridP &G, const Arrays &A, in
 {
     double *rr = rec_row_out(A, G, jl + G.R);
     double code = 0.0;
-    if (on && pm_isfinite(z.x) && pm_isfinite(z.y)) {
+    if (on && pm_isfinite(z.x) && pm_isfinite(z.y) && !(pm_fabs(z.x) < 2047.0 && pm_fabs(z.y) < 2047.0)) {
+        S.overflow = 1;          /* farther than the record code can hold (and than any int conversion should see) */
+    } else if (on && pm_isfinite(z.x) && pm_isfinite(z.y)) {
         double e, mx, my;
         particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
         int bx, by;
@@ -255,11 +262,11 @@ __device__ __forceinline__ void write_record(const GridP &G, const Arrays &A, in
         int r = (bx < 0) ? -bx : bx + 1;
         int ry = (by < 0) ? -by : by + 1;
         S.reach = (r > ry) ? r : ry;
-        if (S.reach <= REC_BIAS - 1) {
+        if (S.reach <= ((G.Rp > 0) ? G.Rp : REACH_CAP)) {
             rr[i] = e; rr[G.Nx + i] = mx; rr[2 * G.Nx + i] = my; rr[3 * G.Nx + i] = wx; rr[4 * G.Nx + i] = wy;
             code = rec_encode((pf & PF_GROUP2) ? 2 : 1, bx, by);
         }
-        if ((G.Rp > 0 && S.reach > G.Rp) || S.reach > REC_BIAS - 1) S.overflow = 1;
+        else { S.overflow = 1; S.reach = 0; }     /* not scattered, not part of the reach the pull follows */
     }
     rr[5 * G.Nx + i] = code;
 }
@@ -533,16 +540,19 @@ __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i
             } else {
                 row = jl + dj + RO;
             }
-            if (!rowok) row = RO;   /* any valid row: the candidate is masked below */
+            if (!rowok) continue;   /* beyond a non-periodic edge: dropped, and nothing is read */
 #pragma unroll 1
             for (int si = 0; si < W; si++) {
                 int qi = si + shx; if (qi >= W) qi -= W;
                 int di = qi - R;
                 int ii = i + di;
-                bool ok = rowok;
-                if (ii < 0) { ok = ok && G.periodic_x; ii += Nx; }
-                else if (ii >= Nx) { ok = ok && G.periodic_x; ii -= Nx; }
-                pull_candidate(rec, (unsigned int)row * rowlen + (unsigned int)ii, pl, di, dj, grp, ok, s0, s1, s2);
+                if (ii < 0 || ii >= Nx) {
+                    /* beyond a non-periodic edge (at ANY distance: the reach may exceed the grid): dropped, nothing
+                     * is read.  Periodic: one wrap suffices, a reach of N/2 or more takes pull_node_aliased. */
+                    if (!G.periodic_x) continue;
+                    ii += (ii < 0) ? Nx : -Nx;
+                }
+                pull_candidate(rec, (unsigned int)row * rowlen + (unsigned int)ii, pl, di, dj, grp, true, s0, s1, s2);
             }
         }
     }

@@ -364,3 +364,41 @@ def test_tripolar_north_fold_bitwise(nx, ny, uv):
         assert_bitwise(g.State, o.State, f"State step {k}")
     assert g.backend.get_counters()["max_reach"] >= 2
     _same_particles(g, o)
+
+
+@pytest.mark.parametrize("periodic", [(False, False), (True, False), (True, True)])
+def test_runaway_particles_are_dropped_safely(periodic):
+    """particles that fly tens, hundreds or thousands of cells in one step (a runaway ODE solution — found with a
+    storm whose winds sit at the 2 m/s gate of the parameterisation): the pull must not read outside its records
+    whatever the reach; beyond the whole-grid reach cap (64 cells) a particle is counted in halo_overflow and not
+    scattered, everything else still scatters exactly."""
+    n = 40
+    def fn():
+        cfg = configs.bench06_box(n=n, dx=1000.0)
+        s = cfg.model["ODEsys"]
+        s.input = s.dissipation = s.peak_shift = s.direction = False
+        g = cfg.model["grid"]
+        cfg.model["grid"] = TwoDCartesianGridMesh(0.0, g.stats.xmax, n, 0.0, g.stats.ymax, n, periodic_boundary=periodic)
+        return cfg
+    g, o = _pair(fn)
+    z = np.zeros((n, n, 5)); z[..., 0] = -3.0
+    on = np.zeros((n, n), dtype=np.uint8)
+    speeds = {(5, 5): (1.0, -0.5), (30, 7): (50.0, 3.0), (8, 31): (-45.0, 58.0),          # reach 1, 31, 35: scattered
+              (20, 20): (150.0, 2.0), (3, 35): (4.0, -900.0), (35, 3): (1e5, 1e5), (11, 12): (-3e9, 1.0)}   # beyond the cap
+    for (i, j), (cx, cy) in speeds.items():
+        on[i, j] = 1
+        z[i, j, 1:3] = [cx, cy]
+    for m in (g, o):
+        m.backend.set_winds(np.zeros((n, n)), np.zeros((n, n)))
+        m.backend.set_particles(z, on)
+        m.backend.zero_state()
+        m.backend.advance(600.0)              # x = c̄x * 600 s / 1000 m cells
+    Sg = g.backend.get_state()
+    c = g.backend.get_counters()
+    assert c["halo_overflow"] == 4 and c["max_reach"] == 35
+    assert np.isfinite(Sg).all()
+    # the oracle has no cap: compare on a run without the four runaways
+    for key in [(20, 20), (3, 35), (35, 3), (11, 12)]:
+        on[key] = 0
+    o.backend.set_particles(z, on); o.backend.zero_state(); o.backend.advance(600.0)
+    assert_bitwise(Sg, o.backend.get_state(), "State without the runaways")
