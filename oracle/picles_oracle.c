@@ -1657,25 +1657,38 @@ static void po_pull_node(po_model *M, int i, int jl, int R, int accum, double s[
     int dxs[W], sxs[W], dys[W], sys[W];
     int nxc = po_axis_candidates(i, Nx, R, M->g.periodic_x, dxs, sxs);
     int nyc = po_axis_candidates(j, Ny, R, M->g.periodic_y == 1, dys, sys);
+    /* sources in ascending index (row, then column); a source reachable through several aliasing offsets (2R+1 > N on
+     * a periodic axis) is visited once, with all its offset pairs (at most one pair matches a corner of it) */
     for (int grp = 1; grp <= M->ngroups; grp++)
-        for (int a = 0; a < nyc; a++) {
-            int dj = dys[a];
-            int row = M->single_slab ? sys[a] + M->R : jl + dj + M->R;
-            const double *rr = po_rec_row(M, row);
-            for (int b = 0; b < nxc; b++) {
-                int di = dxs[b], ii = sxs[b];
-                if (rr[5 * Nx + ii] != (double)grp) continue;
-                int64_t xi[2], yi[2];
-                double xw[2], yw[2];
-                po_index_weight(rr[3 * Nx + ii], 0, xi, xw);
-                po_index_weight(rr[4 * Nx + ii], 0, yi, yw);
-                int ax = (int)(-di - xi[0]), ay = (int)(-dj - yi[0]);
-                if (ax < 0 || ax > 1 || ay < 0 || ay > 1) continue;
-                double w = xw[ax] * yw[ay];
-                s[0] += w * rr[ii];
-                s[1] += w * rr[Nx + ii];
-                s[2] += w * rr[2 * Nx + ii];
+        for (int a0 = 0; a0 < nyc;) {
+            int a1 = a0;
+            while (a1 < nyc && sys[a1] == sys[a0]) a1++;
+            for (int b0 = 0; b0 < nxc;) {
+                int b1 = b0;
+                while (b1 < nxc && sxs[b1] == sxs[b0]) b1++;
+                const int ii = sxs[b0];
+                for (int a = a0; a < a1; a++) {
+                    int dj = dys[a];
+                    int row = M->single_slab ? sys[a] + M->R : jl + dj + M->R;
+                    const double *rr = po_rec_row(M, row);
+                    if (rr[5 * Nx + ii] != (double)grp) continue;
+                    int64_t xi[2], yi[2];
+                    double xw[2], yw[2];
+                    po_index_weight(rr[3 * Nx + ii], 0, xi, xw);
+                    po_index_weight(rr[4 * Nx + ii], 0, yi, yw);
+                    for (int b = b0; b < b1; b++) {
+                        int di = dxs[b];
+                        int ax = (int)(-di - xi[0]), ay = (int)(-dj - yi[0]);
+                        if (ax < 0 || ax > 1 || ay < 0 || ay > 1) continue;
+                        double w = xw[ax] * yw[ay];
+                        s[0] += w * rr[ii];
+                        s[1] += w * rr[Nx + ii];
+                        s[2] += w * rr[2 * Nx + ii];
+                    }
+                }
+                b0 = b1;
             }
+            a0 = a1;
         }
 }
 

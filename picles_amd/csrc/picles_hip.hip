@@ -466,11 +466,13 @@ __device__ __forceinline__ void pull_node_aliased(const GridP &G, const Arrays &
         for (int js = jlo; js <= jhi; js++) {
             int dj0 = js - j;
             if (G.periodic_y) dj0 -= floor_div(dj0 + R, Ny) * Ny;          /* smallest alias >= -R */
-            for (int dj = dj0; dj <= R; dj += (G.periodic_y ? Ny : 2 * R + 1)) {
-                const int row = (wrap_y || !G.periodic_y ? js - G.j_begin : jl + dj) + RO;
-                for (int is = ilo; is <= ihi; is++) {
-                    int di0 = is - i;
-                    if (G.periodic_x) di0 -= floor_div(di0 + R, Nx) * Nx;
+            if (dj0 > R) continue;
+            for (int is = ilo; is <= ihi; is++) {                          /* sources in ascending index ... */
+                int di0 = is - i;
+                if (G.periodic_x) di0 -= floor_div(di0 + R, Nx) * Nx;
+                /* ... each with all its aliasing offsets (at most one pair can match a corner of this source) */
+                for (int dj = dj0; dj <= R; dj += (G.periodic_y ? Ny : 2 * R + 1)) {
+                    const int row = (wrap_y || !G.periodic_y ? js - G.j_begin : jl + dj) + RO;
                     for (int di = di0; di <= R; di += (G.periodic_x ? Nx : 2 * R + 1))
                         pull_candidate(rec, (unsigned int)row * rowlen + (unsigned int)is, pl, di, dj, grp, true, s0, s1, s2);
                 }
@@ -1056,6 +1058,11 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     if (g->j_begin < 0 || g->j_end > g->Ny || g->j_end <= g->j_begin) { g_create_error = "bad slab rows [j_begin,j_end)"; return -2; }
     if (o->solver < 0 || o->solver > 2) { g_create_error = "solver must be 0 (DP5), 1 (Tsit5) or 2 (AutoTsit5(Rosenbrock23()))"; return -3; }
     if (halo_rows < 1) halo_rows = 1;
+    if (halo_rows > 1024) { g_create_error = "halo_rows must be <= 1024"; return -2; }
+    if (!(o->abstol > 0.0) || !(o->reltol >= 0.0) || !(o->maxiters > 0) || !(o->dtmin >= 0.0)) {
+        g_create_error = "ODE settings: abstol > 0, reltol >= 0, maxiters > 0, dtmin >= 0 required";
+        return -3;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -1865,7 +1872,7 @@ PX_EXPORT int32_t picles_halo_rows(const picles_ctx *c) { return c ? c->G.R : -1
 
 PX_EXPORT int32_t picles_set_halo_rows(picles_ctx *c, int32_t r)
 {
-    if (!c || r < 1) return -1;
+    if (!c || r < 1 || r > 1024) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!c->G.single_slab && ((c->G.periodic_y && c->G.Ny <= 2 * r) || c->G.ny_loc < r))

@@ -325,13 +325,21 @@ def test_run_without_observers_uses_one_call_and_matches_stepwise():
     assert np.array_equal(a.State, sb.store.store[-1])
 
 
-@pytest.mark.parametrize("nx,ny,per", [(7, 6, (True, True)), (26, 6, (False, True)), (5, 19, (True, False)), (3, 3, (True, True))])
+@pytest.mark.parametrize("nx,ny,per", [(7, 6, (True, True)), (26, 6, (False, True)), (5, 19, (True, False)), (3, 3, (True, True)),
+                                       (16, 7, (False, True)), (9, 31, (True, False)), (4, 5, (True, True))])
 def test_reach_wrapping_around_a_periodic_axis_bitwise(nx, ny, per):
-    """2R+1 > N on a periodic axis: aliasing offsets; the kernels take the general pull (found by test_gpu_fuzz.py)"""
+    """2R+1 > N on a periodic axis: aliasing offsets; the kernels take the general pull (found by test_gpu_fuzz.py).
+    Node-to-node varying winds make neighbouring sources reach a node through different aliasing offsets
+    (visiting order: test_gpu_hostile.py seed 245)."""
     def cfg():
+        from types import SimpleNamespace
         c = configs.bench06_box(n=8, dx=500.0, U10=9.0, V10=-4.0)
         c.Δt = 1800.0
         c.model["grid"] = TwoDCartesianGridMesh(0.0, 500.0 * (nx - 1), nx, 0.0, 500.0 * (ny - 1), ny, periodic_boundary=per)
+        u0 = lambda x, y, t: 9.0 + 5.0 * np.sin(x / 700.0) * np.cos(y / 900.0)
+        v0 = lambda x, y, t: -4.0 + 6.0 * np.cos(x / 500.0 + y / 1100.0)
+        c.model["winds"] = SimpleNamespace(u=u0, v=v0)
+        c.model["ODEsys"].u, c.model["ODEsys"].v = u0, v0
         return c
     g, o = _pair(cfg)
     for m in (g, o):

@@ -66,7 +66,8 @@ def test_pull_with_large_reach_and_land_mask():
     assert np.all(A[-1][9:13, 10:15, 0][1:-1, 1:-1] >= 0)
 
 
-@pytest.mark.parametrize("nx,ny,per", [(7, 6, (True, True)), (26, 6, (False, True)), (5, 19, (True, False)), (3, 3, (True, True))])
+@pytest.mark.parametrize("nx,ny,per", [(7, 6, (True, True)), (26, 6, (False, True)), (5, 19, (True, False)), (3, 3, (True, True)),
+                                       (16, 7, (False, True)), (9, 31, (True, False)), (4, 5, (True, True))])
 def test_pull_when_the_reach_wraps_around_a_periodic_axis(nx, ny, per):
     """2R+1 > N on a periodic axis (tiny grid, 30-minute steps at 500 m spacing): several offsets alias the same
     source; the pull must still visit sources in the sequential order of the push (found by tests/test_gpu_fuzz.py)."""
@@ -76,6 +77,13 @@ def test_pull_when_the_reach_wraps_around_a_periodic_axis(nx, ny, per):
         c = configs.bench06_box(n=8, dx=500.0, U10=9.0, V10=-4.0)
         c.Δt = 1800.0
         c.model["grid"] = TwoDCartesianGridMesh(0.0, 500.0 * (nx - 1), nx, 0.0, 500.0 * (ny - 1), ny, periodic_boundary=per)
+        # winds that differ from node to node: neighbouring sources of one row reach a node through DIFFERENT
+        # aliasing offsets, which is what exposes a wrong visiting order (tests/test_gpu_hostile.py seed 245)
+        u0 = lambda x, y, t: 9.0 + 5.0 * np.sin(x / 700.0) * np.cos(y / 900.0)
+        v0 = lambda x, y, t: -4.0 + 6.0 * np.cos(x / 500.0 + y / 1100.0)
+        from types import SimpleNamespace
+        c.model["winds"] = SimpleNamespace(u=u0, v=v0)
+        c.model["ODEsys"].u, c.model["ODEsys"].v = u0, v0
         return c
     ma, A = _run(cfg(), False, 5)
     mb, B = _run(cfg(), True, 5)
