@@ -9,15 +9,18 @@
  *   state[3][n]      e, m_x, m_y planes              (reference State[Nx,Ny,3], col-major)
  *   movie[3][n]      MovieState snapshot
  *   z[5][n]          lne, c̄x, c̄y, x, y planes        (ParticleInstance2D.ODEIntegrator.u)
- *   qold[n], dtn[n]  PI-controller memory ln(qold), next dt (<0 => auto_dt_reset!)
+ *   qold[n], dtn[n]  PI-controller memory ln(qold), next dt (<0 => auto_dt_reset!); asw[n] i32 AutoSwitch state (solver 2)
  *   on[n] u8, pflags[n] u8 (bit0 stepped, bit1 group-2 (mask 3), bit2 boundary), status[n] i32
- *   wind u0,v0,u1,v1 [n]
+ *   wind u0,v0,u1,v1 [n] (+ uP,vP: level 0 of the previous window, for fused steps under device-sampled winds)
  *   rec[(ny_loc+2R)][6][Nx]   per-row scatter records e, m_x, m_y, wx_hi, wy_hi, code(list, floor x, floor y)
  *                    (+R ghost rows per side = the halo blocks exchanged between slabs; a row
  *                    block is contiguous, so halo send/recv need no pack/unpack)
  *
  * Kernels and the roofline that bounds each (DESIGN.md has the numbers):
- *   k_advance        fused per-particle step: guards + DP5 adaptive RK of the 5-vector in
+ *   k_step           ONE launch per model step for run!-style steps: pull-scatter + remesh of the previous step,
+ *                    whole adaptive advance of this one, new record.  Flavours (compile time): solver (DP5 / Tsit5 /
+ *                    auto-switching), dead band, static vs time-varying winds, per-node metric.  fp64-VALU bound.
+ *   k_advance        per-particle step alone: guards + adaptive RK of the 5-vector in
  *                    registers + charge/record write.  fp64-VALU bound (~10^4..10^5 flop per
  *                    particle-step against 136 B).  No MFMA: not a contraction.
  *   k_scatter        deterministic PULL scatter (each node sums its <= (2R+1)^2 candidate
