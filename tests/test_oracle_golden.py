@@ -87,15 +87,20 @@ def _periodic_box(case):
 @pytest.mark.parametrize("case,tol_lne", [("cfg1_example00", 1e-3), ("cfg2_T04_5_5", 2e-2), ("cfg2_T04_m10_10", 2e-2),
                                           ("cfg2_T04_10_3", 2e-2), ("cfg3_bench06", 2e-2)])
 @pytest.mark.parametrize("backend", [("libm", 0), ("pmath", 1)])
-def test_converged_anchors(case, tol_lne, backend):
-    """stated tolerance of the DP5(abstol 1e-4, reltol 1e-3) stepper against the converged solution:
+@pytest.mark.parametrize("solver", ["DP5", "Tsit5", "AutoTsit5"])
+def test_converged_anchors(case, tol_lne, backend, solver):
+    """stated tolerance of the (abstol 1e-4, reltol 1e-3) steppers — DP5, Tsit5 and the auto-switching default with its
+    Rosenbrock23 fallback — against the converged solution (SciPy DOP853, rtol 1e-12):
     1e-3 on e for C_phi = 1.81e-5, 2e-2 for C_phi = 0.04"""
     cfg = _periodic_box(case)
+    cfg.model["ODEsets"].solver = solver
     m, S = run_states(cfg, backend, 13)
     steps = GOLD["cases"][case]["steps"]
     for k in (1, 2, 6, 13):
         e = S[k][:, :, 0]
-        assert np.allclose(e, e[0, 0], rtol=1e-12, atol=0), "homogeneous periodic box must stay uniform"
+        # uniform up to the ulp-level differences of the sum order at the periodic wraps, which an adaptive stepper can
+        # amplify by a flipped accept/reject decision (measured: <= 1e-10 for Tsit5 on the stiff generic-direction case)
+        assert np.allclose(e, e[0, 0], rtol=1e-8, atol=0), "homogeneous periodic box must stay uniform"
         assert abs(math.log(e[0, 0]) - steps[k - 1]["lne"]) < tol_lne, (case, k)
     z, on, _, _ = m.backend.get_particles()
     # after remesh the particle carries the node's (lne, c̄): compare c̄ with the anchor
