@@ -630,6 +630,7 @@ __device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i,
     else if ((G.periodic_x && W > G.Nx) || (G.periodic_y && W > G.Ny)) pull_node_aliased(G, A, i, jl, R, s0, s1, s2);
     else if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
     else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
+    else if (R == 3) pull_node<3>(G, A, i, jl, 3, s0, s1, s2);     /* a fully developed sea under strong winds */
     else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
 }
 
