@@ -98,6 +98,11 @@ def test_random_scenario_bitwise(seed):
             else:
                 movie_time_step(m, cfg.Δt)
         a, b = (g.State, o.State) if cfg.mode == "run" else (g.MovieState, o.MovieState)
+        if g.backend.get_counters()["halo_overflow"] > 0:
+            # a runaway particle beyond the whole-grid reach cap (64 cells per step) was dropped by design: the oracle
+            # has no cap, the comparison ends here (test_gpu_hostile.py covers this regime)
+            assert o.backend.get_counters()["max_reach"] > 64
+            return
         assert_bitwise(a, b, f"seed {seed} ({cfg.desc}): step {k}")
     zg, ong, _, stg = g.backend.get_particles()
     zo, ono, _, sto = o.backend.get_particles()

