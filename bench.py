@@ -93,12 +93,13 @@ def measured_traffic(args, world):
     f = ROOT / "profiles" / "r1_pmc_traffic.json"
     try:
         d = json.loads(f.read_text())
-        if world == 1 and d["config"]["n"] == args.n and tuple(d["config"]["winds"]) == tuple(args.winds):
+        if (world == 1 and d["config"]["n"] == args.n and tuple(d["config"]["winds"]) == tuple(args.winds)
+                and args.solver == "DP5" and args.deadband == 0.0 and not args.atomic):
             k = d["kernels"][d["dominant"]]
-            return k["hbm_read_bytes"] + k["hbm_write_bytes"]
+            return k["hbm_read_bytes"] + k["hbm_write_bytes"], k.get("valu_busy"), k.get("valu_insts_per_wave")
     except Exception:
         pass
-    return None
+    return None, None, None
 
 
 def main():
@@ -198,6 +199,7 @@ def main():
         achieved = B_ALG * per_launch / (adv_ms * 1e-3) / 1e9
         rhs_per_ps = rhs_total / (n_total * Ksteps)
         tflops = rhs_total * FLOP_PER_RHS / elapsed / 1e12
+        traffic, valu_busy, valu_per_wave = measured_traffic(args, world)
         out = {
             "metric": "particle_steps_per_sec",
             "value": value,
@@ -223,13 +225,13 @@ def main():
             },
             "hbm_GBps_path": B_ALG * value / 1e9,
             "roofline": {
-                "kernel": "k_step (fused scatter+remesh+advance; k_advance + k_scatter for slabs)",
+                "kernel": "k_step (fused scatter+remesh+advance, one launch per model step; per row range for slabs)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args, world),
+                "traffic": traffic,
                 "avg_launch_ms": adv_ms,
                 "note": "the fused RK advance is fp64-VALU bound, not HBM bound (DESIGN.md): see fp64",
             },
@@ -239,6 +241,9 @@ def main():
                 "achieved_tflops": tflops,
                 "peak_tflops": FP64_PEAK_TFLOPS * world,
                 "frac": tflops / (FP64_PEAK_TFLOPS * world),
+                # from the committed PMC profile of this exact workload (profiles/r1_pmc_summary.md), null otherwise
+                "valu_issue_busy": valu_busy,
+                "valu_insts_per_wave": valu_per_wave,
             },
             "kernel_ms_per_step": {"step_or_advance": tim["advance_ms"] / Ksteps, "scatter_remesh": tim["scatter_ms"] / Ksteps,
                                    "remesh": tim["remesh_ms"] / Ksteps},
