@@ -139,8 +139,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        fallback = None
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # insurance: should RCCL refuse to send / receive straight from the library's record memory (the zero-copy
+            # path cannot be rehearsed on a one-GPU box), all ranks agree over this group to stage the halo blocks
+            # through host memory instead — slower, but the run completes and says so on stderr
+            fallback = dist.new_group(backend="gloo")
         else:
             dist.init_process_group("gloo")
 
@@ -150,7 +155,8 @@ def main():
     cfg = configs.box4096(n=args.n, U10=args.winds[0], V10=args.winds[1])
     cfg.model["ODEsys"].dir_deadband = args.deadband
     cfg.model["ODEsets"].solver = args.solver
-    model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo)
+    model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo,
+                      fallback_group=fallback if world > 1 else None)
     model.seed()
     flags = K.STEP_ZERO_FIRST | (K.STEP_ATOMIC if args.atomic else 0)
     W, Ksteps = args.warmup, args.steps
@@ -219,7 +225,8 @@ def main():
                             f"(C_phi=0.04, gamma=0.88, {args.solver} abstol 1e-4 reltol 1e-3, lne_max=log 27)",
                 "grid": [args.n, args.n],
                 "particles": int(n_total),
-                "parallelism": f"y-slabs x{world}, forward halo of scatter records ({args.halo} row) over RCCL send/recv",
+                "parallelism": f"y-slabs x{world}, forward halo of scatter records ({args.halo} row) over "
+                               + ("RCCL send/recv" if not (world > 1 and model.ex is not None and model.ex.staged) else "host-staged gloo send/recv (fallback)"),
                 "scatter": "atomic-push" if args.atomic else "deterministic-pull",
                 "dir_deadband": args.deadband,
             },

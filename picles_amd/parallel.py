@@ -42,20 +42,24 @@ class _DevBlock:
 class HaloExchange:
     """neighbour exchange of the record halo blocks with torch.distributed"""
 
-    def __init__(self, backend, rank: int, world: int, periodic_y: bool, dist=None, staged=None, host_blocks=False):
+    def __init__(self, backend, rank: int, world: int, periodic_y: bool, dist=None, staged=None, host_blocks=False,
+                 group=None):
         import torch
         import torch.distributed as dist_mod
         self.torch = torch
         self.dist = dist if dist is not None else dist_mod
+        self.group = group                  # None = the default process group
         self.rank, self.world = rank, world
         self.prev = rank - 1 if rank > 0 else (world - 1 if periodic_y else None)
         self.next = rank + 1 if rank < world - 1 else (0 if periodic_y else None)
         if world == 1:
             self.prev = self.next = None
         self.backend = backend
-        be = self.dist.get_backend() if world > 1 else "none"
-        self.staged = (be != "nccl") if staged is None else staged
+        be = self.dist.get_backend(group) if world > 1 else "none"
         self.host_blocks = host_blocks      # the halo blocks are host memory (CPU rehearsal backend)
+        # in place (zero copy) whenever the transport can address the blocks: RCCL on device memory, gloo on host
+        # memory; staged through host tensors otherwise (gloo with the blocks in HBM)
+        self.staged = (be != "nccl" and not host_blocks) if staged is None else staged
         self._bind()
 
     def _bind(self):
@@ -83,7 +87,11 @@ class HaloExchange:
             for k, (p, n) in self.blocks.items():
                 key = (p, n)
                 if key not in self._views:
-                    self._views[key] = torch.as_tensor(_DevBlock(p, n), device="cuda")
+                    if self.host_blocks:    # host memory of the CPU rehearsal backend: a tensor view on it, no copy
+                        arr = np.ctypeslib.as_array((C.c_double * (n // 8)).from_address(p))
+                        self._views[key] = torch.from_numpy(arr)
+                    else:
+                        self._views[key] = torch.as_tensor(_DevBlock(p, n), device="cuda")
                 self.dev[k] = self._views[key]
 
     def rebind(self):
@@ -108,14 +116,18 @@ class HaloExchange:
         ops = []
         # order matters when prev == next (2 ranks, periodic): sends [hi->next, lo->prev],
         # recvs [lo<-prev, hi<-next] pair up correctly on both sides
+        if getattr(self, "_fail_next_inplace", False) and not self.staged:    # test hook: see SlabModel.seed
+            self._fail_next_inplace = False
+            raise RuntimeError("injected failure of the in-place halo exchange")
+        g = self.group
         if self.next is not None:
-            ops.append(dist.P2POp(dist.isend, T["send_hi"], self.next))
+            ops.append(dist.P2POp(dist.isend, T["send_hi"], self.next, group=g))
         if self.prev is not None:
-            ops.append(dist.P2POp(dist.isend, T["send_lo"], self.prev))
+            ops.append(dist.P2POp(dist.isend, T["send_lo"], self.prev, group=g))
         if self.prev is not None:
-            ops.append(dist.P2POp(dist.irecv, T["recv_lo"], self.prev))
+            ops.append(dist.P2POp(dist.irecv, T["recv_lo"], self.prev, group=g))
         if self.next is not None:
-            ops.append(dist.P2POp(dist.irecv, T["recv_hi"], self.next))
+            ops.append(dist.P2POp(dist.irecv, T["recv_hi"], self.next, group=g))
         return dist.batch_isend_irecv(ops)
 
     def finish(self, works):
@@ -135,7 +147,7 @@ class SlabModel:
     `cfg_model` are the WaveGrowth2D keyword arguments (picles_amd.configs)."""
 
     def __init__(self, cfg_model: dict, rank: int, world: int, device: int = 0, halo_rows: int = 1,
-                 backend_factory=None, use_streams=True, exchange=None, auto_halo_every: int = 0):
+                 backend_factory=None, use_streams=True, exchange=None, auto_halo_every: int = 0, fallback_group=None):
         from . import fetch_relations as FetchRelations
         grid, ODEsys, ODEsets = cfg_model["grid"], cfg_model["ODEsys"], cfg_model["ODEsets"]
         self.grid, self.winds = grid, cfg_model["winds"]
@@ -164,6 +176,9 @@ class SlabModel:
         # add a ghost row (collectively) as soon as the reach has used them all — before a particle can overshoot
         self.auto_halo_every = int(auto_halo_every)
         self._steps_done = 0
+        # a second (gloo) process group: if the in-place exchange over the default group fails on ANY rank during the
+        # warm-up in seed(), all ranks agree over this group to stage the halo blocks through host memory instead
+        self.fallback_group = fallback_group
         self._wind_window = None
         self.n_stepped = self._count_stepped()
         self.use_streams = use_streams and world > 1 and backend_factory is None
@@ -214,9 +229,26 @@ class SlabModel:
         if self.ex is not None and not getattr(self, "_comm_warm", False):
             # one throw-away exchange: RCCL builds its P2P channels lazily on first use — keep that
             # out of the first model step (the ghost rows are rewritten by every real exchange)
-            self.ex.finish(self.ex.start())
-            if self.use_streams:
-                self.ex.torch.cuda.synchronize()
+            ok = 1
+            try:
+                self.ex.finish(self.ex.start())
+                if self.use_streams:
+                    self.ex.torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001 — whatever the transport raised
+                if self.fallback_group is None:
+                    raise
+                ok = 0
+                import sys
+                print(f"[picles_amd] rank {self.rank}: in-place halo exchange failed ({e!r}); asking all ranks to stage "
+                      "the halo blocks through host memory", file=sys.stderr, flush=True)
+            if self.fallback_group is not None:
+                import torch.distributed as dist
+                flag = self.ex.torch.tensor([ok], dtype=self.ex.torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.fallback_group)
+                if int(flag[0]) == 0:
+                    self.ex = HaloExchange(self.backend, self.rank, self.world, self.periodic_y, staged=True,
+                                           host_blocks=self.ex.host_blocks, group=self.fallback_group)
+                    self.ex.finish(self.ex.start())
             self._comm_warm = True
             self.backend.seed(0.0)   # restore the zero ghost rows / records the exchange touched
             self.backend.sync()

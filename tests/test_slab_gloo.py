@@ -30,6 +30,8 @@ def _cfg(name):
         return configs.T04_2D_reg_test(U10=-10.0, V10=10.0, periodic=True, n=25, L=96e3)
     if name == "calm":
         return configs.growing_decaying_winds(n=24)
+    if name == "fallback":
+        return configs.bench06_box(n=24, dx=1500.0)
     if name == "growing_reach":           # 1.4 km spacing: the developing sea's scatter reach passes from 1 to 2 cells at step 11
         return configs.bench06_box(n=24, dx=1400.0)
     raise KeyError(name)
@@ -46,8 +48,15 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
 
     cfg = _cfg(name)
     auto = 1 if name == "growing_reach" else 0
-    model = SlabModel(cfg.model, rank, world, halo_rows=halo, backend_factory=fac, auto_halo_every=auto)
+    fb = dist.new_group(backend="gloo") if name == "fallback" else None
+    model = SlabModel(cfg.model, rank, world, halo_rows=halo, backend_factory=fac, auto_halo_every=auto, fallback_group=fb)
+    assert model.ex.staged is False            # the CPU rehearsal exchanges in place too: P2P straight on the halo blocks
+    if name == "fallback":
+        model.ex._fail_next_inplace = True      # the in-place exchange fails during the warm-up (on every rank alike:
+                                                # a rank that failed alone would leave its neighbours waiting) ...
     model.seed()
+    if name == "fallback":
+        assert model.ex.staged is True          # ... and every rank has switched to staging, collectively
     for _ in range(n_steps):
         model.time_step(cfg.Δt)
     S = model.gather_state()
@@ -78,6 +87,7 @@ def _single(name, n_steps):
 
 @pytest.mark.parametrize("name,world,halo", [("periodic", 2, 1), ("periodic", 3, 2), ("nonperiodic_generic", 2, 1),
                                              ("periodic_model_ring", 3, 1), ("calm", 2, 2)])
+@pytest.mark.timeout(180)
 def test_slabs_equal_single_domain(tmp_path, name, world, halo):
     n_steps = 4
     port = _free_port()
@@ -88,6 +98,18 @@ def test_slabs_equal_single_domain(tmp_path, name, world, halo):
     assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
 
 
+@pytest.mark.timeout(180)
+def test_failed_inplace_exchange_falls_back_to_staging_on_all_ranks(tmp_path):
+    """bench.py gives SlabModel a second (gloo) group: if the in-place exchange raises during the warm-up (the transport
+    refusing the library's memory would do so on every rank), all ranks agree to stage the halo blocks through host
+    memory; the run stays bitwise"""
+    n_steps = 4
+    mp.spawn(_worker, args=(3, _free_port(), "fallback", n_steps, 1, str(tmp_path)), nprocs=3, join=True)
+    S = np.load(tmp_path / "state.npy")
+    assert np.array_equal(S, _single("fallback", n_steps))
+
+
+@pytest.mark.timeout(180)
 def test_halo_rows_grow_with_the_reach(tmp_path):
     """auto_halo_every: a run that starts with one ghost row and whose reach passes 2 cells never overflows"""
     n_steps = 14
