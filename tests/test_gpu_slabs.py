@@ -54,6 +54,7 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
 
 @pytest.mark.parametrize("name,world,halo", [("periodic", 2, 1), ("periodic", 3, 2), ("nonperiodic_generic", 2, 1), ("calm", 2, 2),
                                              ("periodic_model_ring", 3, 1), ("sphere", 2, 2)])
+@pytest.mark.timeout(300)
 def test_gpu_slabs_equal_single_context(tmp_path, name, world, halo):
     from picles_amd.parallel import SlabModel
     n_steps = 4
@@ -68,6 +69,7 @@ def test_gpu_slabs_equal_single_context(tmp_path, name, world, halo):
     assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
 
 
+@pytest.mark.timeout(300)
 def test_gpu_halo_rows_grow_with_the_reach(tmp_path):
     """auto_halo_every on the HIP library (fused slab steps, ghost rows re-packed mid-run): the reach passes from 1
     to 2 cells at step 11 of this box; the run starts with one ghost row and must never overflow"""
