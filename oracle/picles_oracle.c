@@ -654,7 +654,7 @@ static double po_dp5_try_e(const po_model *M, int64_t idx, const double u0[5], c
             nu = PO_FMA(a, a, nu);
             nd = PO_FMA(b, b, nd);
         }
-        *eigen_est = sqrt(nu / nd);
+        eigen_est[0] = nu; eigen_est[1] = nd;      /* eigen_est² = nu/nd: the stiffness test needs no more */
     }
 #undef STAGE
     double at[5], sc[5];
@@ -961,7 +961,7 @@ static void po_integrate_auto(const po_model *M, int64_t idx, double z[5], doubl
         dt = po_initdt(M, idx, z, k1, t_start, st);
     }
     const double beta1 = 0.14, beta2 = 0.08;
-    double eig = 0.0;
+    double eig[2] = {0.0, 1.0};      /* eigen_est² = eig[0] / eig[1] */
     int have_eig = 0;
     int64_t iter = 0;
     while (tr < DT) {
@@ -971,7 +971,8 @@ static void po_integrate_auto(const po_model *M, int64_t idx, double z[5], doubl
         if (fresh) {
             fresh = 0;                 /* first call: current = nonstiff, no test */
         } else if (have_eig) {
-            int pos = fabs(eig * dt * (1.0 / ASW_STABILITY)) > 0.9;
+            /* |eigen_est dt / 3.5068| > 0.9  <=>  nu dt² > (0.9·3.5068)² nd  (a NaN on either side: not stiff) */
+            int pos = eig[0] * (dt * dt) > ((0.9 * ASW_STABILITY) * (0.9 * ASW_STABILITY)) * eig[1];
             count = pos ? (count < 0 ? 1 : count + 1) : (count > 0 ? -1 : count - 1);
             if (!stiff && count > 10) { dt = dt * 2.0; stiff = 1; }
             else if (stiff && count < -3) { dt = dt * 0.5; stiff = 0; }
@@ -981,11 +982,15 @@ static void po_integrate_auto(const po_model *M, int64_t idx, double z[5], doubl
         double h = (dt < rem) ? dt : rem;
         int last = !(dt < rem);
         double EE2;
-        if (stiff) EE2 = po_ros23_try(M, idx, z, k1, t_start + tr, h, unew, kn, st, &eig);
-        else EE2 = po_dp5_try_e(M, idx, z, k1, t_start + tr, h, unew, kn, st, &eig);
+        if (stiff) {
+            double nj;
+            EE2 = po_ros23_try(M, idx, z, k1, t_start + tr, h, unew, kn, st, &nj);
+            eig[0] = nj * nj; eig[1] = 1.0;        /* ||J||_inf */
+        } else {
+            EE2 = po_dp5_try_e(M, idx, z, k1, t_start + tr, h, unew, kn, st, eig);
+        }
         have_eig = 1;
         if (!M->order && !stiff) EE2 = EE2 * EE2;     /* the literal-order explicit pair returns EEst; Rosenbrock returns EEst² */
-        if (!(eig == eig)) eig = 0.0;
         if (!(EE2 == EE2)) { EE2 = INFINITY; st->status |= PICLES_ST_NONFINITE; }
         int accept = (EE2 <= 1.0) || (od->force_dtmin && h <= od->dtmin);
         double le = 0.5 * o_log_coarse(EE2);

@@ -678,7 +678,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     long long iter = 0;
     bool as_fresh = false, as_stiff = false, have_eig = false;
     int as_count = 0;
-    double eig = 0.0;
+    double eig = 0.0, eig_nu = 0.0, eig_nd = 1.0;   /* eigen_est² = eig_nu / eig_nd */
     if (AUTO) {
         as_fresh = (*asw == ASW_FRESH);
         as_stiff = as_fresh ? false : ((*asw & 1) != 0);
@@ -691,7 +691,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             if (as_fresh) {
                 as_fresh = false;
             } else if (have_eig) {
-                bool pos = pm_fabs(eig * dt * (1.0 / ASW_STABILITY)) > 0.9;
+                /* |eigen_est dt / 3.5068| > 0.9  <=>  nu dt² > (0.9·3.5068)² nd  (a NaN on either side: not stiff) */
+                bool pos = eig_nu * (dt * dt) > ((0.9 * ASW_STABILITY) * (0.9 * ASW_STABILITY)) * eig_nd;
                 as_count = pos ? (as_count < 0 ? 1 : as_count + 1) : (as_count > 0 ? -1 : as_count - 1);
                 if (!as_stiff && as_count > 10) { dt = dt * 2.0; as_stiff = true; }
                 else if (as_stiff && as_count < -3) { dt = dt * 0.5; as_stiff = false; }
@@ -706,6 +707,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         double EE2;
         if (AUTO && as_stiff) {
             EE2 = ros23_try<FAST, STATIC, METRIC, DB>(P, w, W, z, k1, t, h, ipx, ipy, pc, un, k7, eig, st);
+            eig_nu = eig * eig; eig_nd = 1.0;     /* ||J||_inf */
         } else {
         double gl, gx, gy;      /* stage state (lne, c̄x, c̄y) */
         /* x,y tendencies are c̄x/Δx, c̄y/Δy of the stage state: their tableau sums run on the stage
@@ -769,7 +771,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             a = k7.cy - k6.cy; b = un.cy - gy; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
             a = un.cx * ipx - gx * ipx; b = un.x - g6x; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
             a = un.cy * ipy - gy * ipy; b = un.y - g6y; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
-            eig = __builtin_sqrt(nu / nd);
+            eig_nu = nu; eig_nd = nd;     /* the test below needs eigen_est² = nu/nd only: no sqrt, no division */
         }
         ex = PM_FMA(TT(e7), un.cx, ex) * ipx; ey = PM_FMA(TT(e7), un.cy, ey) * ipy;
 #define E12(c) (has2 ? PM_FMA(TT(e2), k2.c, TT(e1) * k1.c) : TT(e1) * k1.c)
@@ -803,7 +805,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #undef S72
 #undef E12
         }   /* explicit pair */
-        if (AUTO) { have_eig = true; if (!(eig == eig)) eig = 0.0; }
+        if (AUTO) have_eig = true;
         if (!(EE2 == EE2)) { EE2 = pm_inf(); st.status |= 128 /*PICLES_ST_NONFINITE*/; }
         /* PI controller in log space (kernel order): 1/q = γ·qold^β2 / EEst^β1, clamped to
          * [qmin, qmax]; lq = ln(qold) is the carried controller memory. One log + one exp per step. */
