@@ -30,6 +30,11 @@ def hip_lib():
 
 
 @pytest.fixture(scope="session", autouse=True)
-def _oracle_built():
+def _natives_built():
+    """a fresh clone has no binaries: build the checker (oracle) and the product library (hipcc cross-compiles gfx950
+    without a GPU; make is a no-op when they are current).  Building is all that happens here — the product has no CPU
+    path and the GPU tests fail loudly without a device."""
+    import subprocess
     import _oracle
     _oracle.build()
+    subprocess.run(["make", "-s", "-C", str(ROOT / "picles_amd" / "csrc"), "libpicles_hip.so"], check=True)
