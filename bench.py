@@ -134,7 +134,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     if args.backend == "gloo":
-        local_rank = 0            # rehearsal: every rank on the one GPU
+        local_rank = 0            # rehearsal: every rank on the one GPU (RCCL itself refuses two ranks per device)
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist

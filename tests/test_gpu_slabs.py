@@ -119,3 +119,51 @@ def test_halo_blocks_are_zero_copy_torch_views():
     hm.scatter_remesh()
     S = hm.get_state()
     assert S[:, 0, 0].min() > S[:, 8, 0].min() * 0.5  # edge row received contributions from the ghost rows
+
+
+def _nccl_self_worker(rank, port, outdir):
+    """one-rank RCCL group: send the library's own halo block to ourselves and receive it into a ghost block, in
+    place — the mechanics of the multi-GPU exchange (torch P2P ops on views of library memory) on the one GPU we have"""
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    from picles_amd import configs, _capi as K
+    from picles_amd.models import build_structs
+    from picles_amd.driver import HipModel
+    from picles_amd.parallel import _DevBlock
+    from picles_amd import fetch_relations as FR
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    cfg = configs.bench06_box(n=32)
+    ms = FR.MinimalState(2, 2, cfg.model["ODEsets"].timestep)
+    g, p, o, m = build_structs(cfg.model["grid"], cfg.model["ODEsys"], cfg.model["ODEsets"], None, ms, True, j_begin=8, j_end=24)
+    hm = HipModel(g, p, o, m, mask=cfg.model["grid"].data.mask, device=0, halo_rows=2)
+    w = np.full((32, 16), 10.0)
+    hm.set_winds(w, w, 0.0)
+    hm.seed(0.0)
+    hm.begin_step(600.0, K.STEP_ZERO_FIRST)
+    s_edge = torch.cuda.Stream()
+    hm.advance_rows(K.ROWS_ALL, s_edge.cuda_stream)
+    sp, sn = hm.halo_send(1)
+    rp, rn = hm.halo_recv(0)
+    send = torch.as_tensor(_DevBlock(sp, sn), device="cuda")
+    recv = torch.as_tensor(_DevBlock(rp, rn), device="cuda")
+    with torch.cuda.stream(s_edge):            # RCCL orders itself after the kernel on this stream
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, send, 0), dist.P2POp(dist.irecv, recv, 0)])
+        for wk in works:
+            wk.wait()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(send, recv)) and bool((send.view(2, 6, 32)[:, 5, :] != 0).all())
+    hm.scatter_remesh()                          # the scatter now pulls from the ghost rows RCCL wrote
+    S = hm.get_state()
+    np.save(os.path.join(outdir, "ok.npy"), np.array([ok, np.isfinite(S).all()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_moves_halo_blocks_in_place(tmp_path):
+    """the zero-copy mechanics of the multi-GPU path on real hardware: a one-rank RCCL process group sends the edge rows
+    of the library's record memory to itself and receives them into the ghost rows (torch.distributed P2P ops on
+    __cuda_array_interface__ views, ordered after the advance kernel on the same stream)"""
+    mp.spawn(_nccl_self_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    ok = np.load(tmp_path / "ok.npy")
+    assert ok[0] and ok[1]
