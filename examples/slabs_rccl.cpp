@@ -62,7 +62,10 @@ int main(int argc, char **argv)
     std::vector<ncclComm_t> comms(world);
     std::vector<int> devs(world);
     for (int r = 0; r < world; r++) devs[r] = r;
-    if (world > 1) NCCL_OK(ncclCommInitAll(comms.data(), world, devs.data()));
+    /* PICLES_RCCL_SELF=1: with one GPU, still open a communicator and run the exchange against ourselves (exercises the
+     * RCCL calls on the library's memory; the whole-grid context does not read its ghost rows) */
+    const bool use_rccl = world > 1 || (getenv("PICLES_RCCL_SELF") && atoi(getenv("PICLES_RCCL_SELF")) == 1);
+    if (use_rccl) NCCL_OK(ncclCommInitAll(comms.data(), world, devs.data()));
 
     /* bench06 physics (benchmark/bench06_homogenous_box_brenchmarlk.jl:47-126): C_phi = c_beta, gamma 0.88, DP5 */
     const double r_g = 0.85, c_D = 2e-3, c_beta = 4e-2, c_e = 1.3e-6, c_alpha = 11.8, r_w = 2.35, q = -0.25;
@@ -104,7 +107,7 @@ int main(int argc, char **argv)
             HIP_OK(hipStreamWaitEvent(sE, evM, 0));
             if (fused == 0) PIC_OK(ctx, picles_step_rows(ctx, PICLES_ROWS_EDGE, sE));
             else PIC_OK(ctx, picles_advance_rows(ctx, PICLES_ROWS_EDGE, sE));
-            if (world > 1) {
+            if (use_rccl) {
                 void *s_lo, *s_hi, *r_lo, *r_hi;
                 size_t b;
                 PIC_OK(ctx, picles_halo_send_dev(ctx, 0, &s_lo, &b));
@@ -152,6 +155,6 @@ int main(int argc, char **argv)
     for (int r = 0; r < world; r++) { tmax = std::max(tmax, secs[r]); total += advanced[r]; }
     printf("{\"n_gpus\": %d, \"grid\": %d, \"steps\": %d, \"ms_per_step\": %.4f, \"particle_steps_per_s\": %.4e}\n",
            world, N, steps, 1e3 * tmax / steps, (double)total / tmax);
-    if (world > 1) for (auto &c : comms) ncclCommDestroy(c);
+    if (use_rccl) for (auto &c : comms) ncclCommDestroy(c);
     return 0;
 }

@@ -295,10 +295,13 @@ def test_native_slab_driver_builds_and_runs(tmp_path):
     subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", str(root / "include"),
                     str(root / "examples" / "slabs_rccl.cpp"), "-o", str(exe), "-L", str(lib), "-lpicles_hip",
                     f"-Wl,-rpath,{lib}", "-lrccl", "-lpthread"], check=True)
-    out = subprocess.run([str(exe), "1", "256", "6"], check=True, capture_output=True, text=True, timeout=120).stdout
-    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["grid"] == 256 and d["steps"] == 6
-    assert d["particle_steps_per_s"] > 1e8
+    import os
+    for self_exchange in ("0", "1"):            # "1": RCCL communicator of one rank, halo blocks sent to ourselves
+        out = subprocess.run([str(exe), "1", "256", "6"], check=True, capture_output=True, text=True, timeout=180,
+                             env=dict(os.environ, PICLES_RCCL_SELF=self_exchange)).stdout
+        d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 1 and d["grid"] == 256 and d["steps"] == 6
+        assert d["particle_steps_per_s"] > 1e8
 
 
 def test_mixed_call_sequences_keep_parity():
