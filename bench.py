@@ -119,6 +119,9 @@ def main():
                     help="opt-in picles_phys.dir_deadband (0 = reference-exact RHS; the headline number uses 0)")
     ap.add_argument("--solver", default="DP5", choices=["DP5", "Tsit5", "AutoTsit5"],
                     help="ODE solver of the workload (the BASELINE box is quoted on DP5, as benchmarks/bench06 sets it)")
+    ap.add_argument("--ring-of-one", action="store_true",
+                    help="rehearsal on ONE GPU of the N > 1 host loop over the real transport: a one-rank RCCL group, edge / "
+                         "interior launches on two streams, the halo blocks sent to ourselves every step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")
     args = ap.parse_args()
@@ -149,6 +152,13 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if world == 1 and args.ring_of_one:
+        import socket
+        import torch.distributed as dist
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
+
     from picles_amd import configs, _capi as K
     from picles_amd.parallel import SlabModel
 
@@ -156,7 +166,7 @@ def main():
     cfg.model["ODEsys"].dir_deadband = args.deadband
     cfg.model["ODEsets"].solver = args.solver
     model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo,
-                      fallback_group=fallback if world > 1 else None)
+                      fallback_group=fallback if world > 1 else None, ring_of_one=args.ring_of_one)
     model.seed()
     flags = K.STEP_ZERO_FIRST | (K.STEP_ATOMIC if args.atomic else 0)
     W, Ksteps = args.warmup, args.steps
@@ -263,6 +273,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif args.ring_of_one:
         dist.destroy_process_group()
 
 

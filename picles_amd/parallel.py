@@ -43,7 +43,7 @@ class HaloExchange:
     """neighbour exchange of the record halo blocks with torch.distributed"""
 
     def __init__(self, backend, rank: int, world: int, periodic_y: bool, dist=None, staged=None, host_blocks=False,
-                 group=None):
+                 group=None, self_ring=False):
         import torch
         import torch.distributed as dist_mod
         self.torch = torch
@@ -53,9 +53,11 @@ class HaloExchange:
         self.prev = rank - 1 if rank > 0 else (world - 1 if periodic_y else None)
         self.next = rank + 1 if rank < world - 1 else (0 if periodic_y else None)
         if world == 1:
-            self.prev = self.next = None
+            # one rank: nothing to exchange — unless asked to run the ring against ourselves (rehearsal of the N > 1
+            # host logic and of the transport on one GPU; the whole-grid context does not read its ghost rows)
+            self.prev = self.next = (0 if (self_ring and periodic_y) else None)
         self.backend = backend
-        be = self.dist.get_backend(group) if world > 1 else "none"
+        be = self.dist.get_backend(group) if (world > 1 or self_ring) else "none"
         self.host_blocks = host_blocks      # the halo blocks are host memory (CPU rehearsal backend)
         # in place (zero copy) whenever the transport can address the blocks: RCCL on device memory, gloo on host
         # memory; staged through host tensors otherwise (gloo with the blocks in HBM)
@@ -99,7 +101,7 @@ class HaloExchange:
 
     def start(self):
         """post the sends/recvs; returns the work handles (call inside the edge stream context)"""
-        if self.world == 1 or (self.prev is None and self.next is None):
+        if self.prev is None and self.next is None:
             return []
         self._bind()
         dist = self.dist
@@ -147,7 +149,8 @@ class SlabModel:
     `cfg_model` are the WaveGrowth2D keyword arguments (picles_amd.configs)."""
 
     def __init__(self, cfg_model: dict, rank: int, world: int, device: int = 0, halo_rows: int = 1,
-                 backend_factory=None, use_streams=True, exchange=None, auto_halo_every: int = 0, fallback_group=None):
+                 backend_factory=None, use_streams=True, exchange=None, auto_halo_every: int = 0, fallback_group=None,
+                 ring_of_one=False):
         from . import fetch_relations as FetchRelations
         grid, ODEsys, ODEsets = cfg_model["grid"], cfg_model["ODEsys"], cfg_model["ODEsets"]
         self.grid, self.winds = grid, cfg_model["winds"]
@@ -181,13 +184,15 @@ class SlabModel:
         self.fallback_group = fallback_group
         self._wind_window = None
         self.n_stepped = self._count_stepped()
-        self.use_streams = use_streams and world > 1 and backend_factory is None
+        ring_of_one = bool(ring_of_one) and world == 1 and self.periodic_y
+        self.use_streams = use_streams and (world > 1 or ring_of_one) and backend_factory is None
         if exchange is not None:          # caller-supplied exchange object (start() / finish(works)), e.g. several slabs in one process
             self.ex = exchange
             self.use_streams = False
         else:
-            self.ex = (HaloExchange(self.backend, rank, world, self.periodic_y, host_blocks=backend_factory is not None)
-                       if world > 1 else None)
+            self.ex = (HaloExchange(self.backend, rank, world, self.periodic_y, host_blocks=backend_factory is not None,
+                                    self_ring=ring_of_one)
+                       if (world > 1 or ring_of_one) else None)
         if self.use_streams:
             import torch
             self.s_edge = torch.cuda.Stream()
@@ -257,7 +262,7 @@ class SlabModel:
     def time_step(self, dt, flags=K.STEP_ZERO_FIRST):
         self.upload_winds(self.clock, dt)
         b = self.backend
-        if self.world == 1:
+        if self.ex is None:
             b.time_step(dt, flags)
         elif self.use_streams:
             torch = self.ex.torch
