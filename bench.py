@@ -145,10 +145,9 @@ def main():
         fallback = None
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            # insurance: should RCCL refuse to send / receive straight from the library's record memory (the zero-copy
-            # path cannot be rehearsed on a one-GPU box), all ranks agree over this group to stage the halo blocks
-            # through host memory instead — slower, but the run completes and says so on stderr
-            fallback = dist.new_group(backend="gloo")
+            # (SlabModel can fall back to host-staged halos over a second gloo group — fallback_group — if the in-place
+            # exchange raises at warm-up; not opened here: RCCL send/recv straight from the library's record memory is
+            # exercised on this stack by the ring-of-one test, and a second rendezvous is one more thing that can stall)
         else:
             dist.init_process_group("gloo")
 
