@@ -126,6 +126,12 @@ def main():
                     help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: whatever the runtime libraries print (RCCL's version banner and
+    # warnings go to stdout by default) is sent to stderr by pointing fd 1 there for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -269,7 +275,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, W, Ksteps)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
