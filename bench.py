@@ -181,8 +181,10 @@ def main():
     model.backend.reset_counters()
     model.backend.enable_timing(True)
 
+    use_dist = world > 1 or args.ring_of_one      # the ring of one exercises the same collectives on its one-rank group
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         model.sync()
@@ -200,7 +202,7 @@ def main():
     vals = torch.tensor([elapsed, float(n_local), float(cnt["rhs_evals"]), float(cnt["halo_overflow"]),
                          float(cnt["steps_accepted"]), float(cnt["steps_rejected"])], dtype=torch.float64,
                         device="cuda" if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if use_dist:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
@@ -277,10 +279,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
+    if use_dist:
         dist.barrier()
-        dist.destroy_process_group()
-    elif args.ring_of_one:
         dist.destroy_process_group()
 
 

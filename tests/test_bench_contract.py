@@ -46,3 +46,17 @@ def test_live_bench_prints_one_json_line():
     d = json.loads(lines[0])
     _check(d, need_cpu=True)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["config"]["particles"] == 256 * 256
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_ring_of_one_bench_prints_one_json_line():
+    """the N > 1 flow of bench.py (RCCL process group, barrier + all-reduce of the timings, per-step halo exchange) on a
+    one-rank group: stdout still carries exactly one JSON line although RCCL prints its banner"""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--ring-of-one", "--steps", "4", "--warmup", "1",
+                          "--grid-n", "256", "--no-cpu"], check=True, capture_output=True, text=True).stdout
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    _check(d, need_cpu=False)
+    assert d["n_gpus"] == 1 and d["steps"] == 4
