@@ -25,6 +25,30 @@ def const_winds(U10, V10):
     return SimpleNamespace(u=u, v=v)
 
 
+def smooth_winds(U10, V10, Lx, Ly, a=0.2, b=0.15, direction=True, band=None):
+    """Time-constant winds with a smooth, periodic-compatible perturbation of period (Lx, Ly), so that neighbouring
+    nodes differ (the full-size parity tests: a wrong-neighbour read is invisible in a homogeneous box).
+    direction=True: speed and direction vary; False: u/v keeps the ratio U10/V10 (speed only).
+    band=(y0, y1): the direction varies only for y0 <= y < y1 (speed everywhere)."""
+    def s(x, y):
+        return 1.0 + a * np.sin(2 * np.pi * x / Lx) * np.cos(2 * np.pi * y / Ly)
+
+    def d(x, y):
+        r = 1.0 + b * np.cos(2 * np.pi * x / Lx + 0.3) * np.sin(4 * np.pi * y / Ly)
+        if not direction:
+            return 1.0 + 0 * x
+        if band is not None:
+            return np.where((y >= band[0]) & (y < band[1]), r, 1.0)
+        return r
+
+    def u(x, y, t):
+        return U10 * s(x, y)
+
+    def v(x, y, t):
+        return V10 * s(x, y) * d(x, y)
+    return SimpleNamespace(u=u, v=v)
+
+
 def example_00_minimal(n=51, L=100e3, U10=10.0, V10=10.0):
     """examples/example_00_minimal.jl:18-67 — 51×51, 100 km box, winds (10,10), DT = 10 min,
     run!(stop_time = 2 h) => 13 steps, non-periodic grid, periodic_boundary = false,
@@ -43,12 +67,12 @@ def example_00_minimal(n=51, L=100e3, U10=10.0, V10=10.0):
         Δt=DT, stop_time=2 * HOURS, n_steps=13, mode="run")
 
 
-def T04_2D_reg_test(n=31, L=120e3, U10=5.0, V10=5.0, periodic=False, n_steps=36):
+def T04_2D_reg_test(n=31, L=120e3, U10=5.0, V10=5.0, periodic=False, n_steps=36, winds=None):
     """tests/T04_2D_reg_test.jl:40-151 — 4 km spacing, C_φ = c_β = 0.04 (:64-65),
     movie_time_step! × 36, periodic ∈ {true,false} is the MODEL flag on a non-periodic grid.
     BASELINE config 2 scales it to 256×256 (n=256, L=255*4000)."""
     DT = 10 * MINUTES
-    winds = const_winds(U10, V10)
+    winds = const_winds(U10, V10) if winds is None else winds
     grid = TwoDCartesianGridMesh(L, n, L, n)
     ODEpars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
     psys = particle_equations(winds.u, winds.v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
@@ -64,13 +88,13 @@ def T04_2D_reg_test(n=31, L=120e3, U10=5.0, V10=5.0, periodic=False, n_steps=36)
         Δt=DT, n_steps=n_steps, mode="movie")
 
 
-def bench06_box(n=1024, dx=2000.0, U10=10.0, V10=10.0, n_steps=100, periodic_grid=True):
+def bench06_box(n=1024, dx=2000.0, U10=10.0, V10=10.0, n_steps=100, periodic_grid=True, winds=None):
     """benchmark/bench06_homogenous_box_brenchmarlk.jl:47-126 scaled per BASELINE configs 3/4:
     γ = 0.88 passed explicitly (:72), C_φ = c_β = 0.04 (:77), DP5, lne_max = log 27, dt0 = 10,
     dtmin = 1, force_dtmin, seed time-scale 30 min (:49,96), model Δt = 10 min (:126); fully
     periodic grid + periodic_boundary = true (BASELINE's choice; the file itself is non-periodic)."""
     DT_seed = 30 * MINUTES
-    winds = const_winds(U10, V10)
+    winds = const_winds(U10, V10) if winds is None else winds
     L = dx * (n - 1)
     grid = TwoDCartesianGridMesh(L, n, L, n, periodic_boundary=(periodic_grid, periodic_grid))
     Const_ID = IDConstants.make()

@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/step2d_*.npz: a THIRD opinion on the whole 2D model step.
+
+Plain NumPy + SciPy restatement of one `time_step!` of the reference on a small NON-uniform case —
+24×20 mesh, periodic in x / open in y, a land block, spatially (and, in one case, temporally) varying
+winds with a calm band — written from the reference's Julia sources alone.  Nothing here imports
+`oracle/`, `picles_amd/` or the HIP library; the tests then hold oracle A (libm, literal order), oracle B
+(pmath, kernel order) and the HIP path against these files.
+
+What is restated (reference file:line):
+  mask classes / ocean_points   src/Grids/mask_utils.jl:14-82, src/Models/WaveGrowthModels2D.jl:256-270
+  init_particles! / SeedParticle src/Simulations/run.jl:199-247, src/Operators/core_2D.jl:247-288,360-366,434-488
+  get_initial_windsea, Minimal*  src/FetchRelations.jl:128-203,314-415
+  particle_system (RHS)          src/ParticleSystems/particle_waves_v5.jl:479-556 (+ helpers :212-351)
+  advance! (guards, off->on)     src/Operators/mapping_2D.jl:118-243
+  ParticleToNode!/push_to_grid!  src/Operators/mapping_2D.jl:59-73, src/ParticleInCell.jl:58-71,341-376,444-466,504-508
+  NodeToParticle! (A-D)          src/Operators/mapping_2D.jl:279-356, src/Operators/core_2D.jl:69-78,121-128
+  time_step!, run! zeroing       src/Operators/TimeSteppers.jl:109-166, src/Simulations/run.jl:72-114
+
+`step!(integrator, DT, true)` (OrdinaryDiffEq, third-party, not in the reference tree) is replaced by the
+CONVERGED solution: scipy `solve_ivp(DOP853, rtol 1e-12, atol 1e-14)`.  A tolerance-respecting stepper
+(abstol 1e-4, reltol 1e-3) sits within 1e-3 (C_phi = 1.81e-5) / 2e-2 (C_phi = 0.04) of it on `e`
+(SURVEY Appendix D.2); the propagation-only case has an exact solution (c̄ constant, x = c̄ t / Δx), so
+there the particle-in-cell and remesh semantics are pinned to rounding.
+
+Decisions on reference quirks taken the same way as the build: `on` flags persist
+(B.3), every particle uses the model clock (B.4), `round(x, digits=6)` is Julia's `rint(x*1e6)/1e6`,
+MinimalWindsea's random sign is +1 (B.9).
+
+Run:  python tests/golden/make_step2d_fixture.py     (about 5 minutes; the .npz files are the fixtures)
+"""
+import math
+from pathlib import Path
+
+import numpy as np
+from scipy.integrate import solve_ivp
+
+HERE = Path(__file__).resolve().parent
+
+
+# ---------------------------------------------------------------- FetchRelations.jl
+def get_initial_windsea(U10, V10, T):
+    A, xi0, qx = 22.8013, 2.4097, 0.2748
+    Ua = math.sqrt(U10 ** 2 + V10 ** 2)
+    Ua = 0.1 if Ua < 0.1 else Ua
+    tau = 9.81 * abs(T) / abs(Ua)
+    X = (tau / (A * xi0)) ** (1 / (1 - qx))          # X_tilde_from_tau :128
+    fm = 3.5 * (9.81 / Ua) * X ** (-0.33)            # fₘ_from_X_tilde :165
+    aj = 0.033 * (fm * Ua / 9.81) ** 0.67            # alpha_j :184
+    E = 0.31 * 9.81 ** 2 * aj * (fm * 2 * math.pi) ** (-4)   # E_JONSWAP :201
+    f_peak = fm * 9.81 / Ua
+    T_bar = 0.9 * (1 / f_peak)
+    cg = 9.81 * T_bar / (4 * math.pi)
+    cx, cy = cg * U10 / Ua, cg * V10 / Ua
+    return dict(lne=math.log(E), cx=cx, cy=cy, E=E, mx=U10 / Ua * E / (2 * cg), my=V10 / Ua * E / (2 * cg))
+
+
+def minimal_windsea(U10, V10, T):
+    U10 = 1.0 if U10 == 0 else U10
+    V10 = 1.0 if V10 == 0 else V10
+    a = math.sqrt(U10 ** 2 + V10 ** 2)
+    return get_initial_windsea(1.0 * U10 / a, 1.0 * V10 / a, T)
+
+
+def minimal_state(U10, V10, T):
+    w = minimal_windsea(U10, V10, T)
+    return [w["E"], w["mx"] ** 2 + w["my"] ** 2]
+
+
+# ---------------------------------------------------------------- particle_waves_v5.jl
+def id_constants(r_g=0.85, c_D=2e-3, c_beta=4e-2, c_e=1.3e-6, c_alpha=11.8, r_w=2.35, q=-0.25):
+    p = (-1 - 10 * q) / 2
+    n = 2 * q / (p + 4 * q)
+    C_e = r_w * c_beta * c_D / r_g
+    gamma = 1 - (p - q) / (c_alpha ** 4 * C_e * 2)
+    return dict(r_g=r_g, c_D=c_D, c_beta=c_beta, c_e=c_e, c_alpha=c_alpha, C_e=C_e, gamma=gamma, q=q, p=p, n=n)
+
+
+def make_rhs(uf, vf, idc, C_alpha, C_phi, inv_dx, inv_dy, sw):
+    """particle_system(dz, z, params, t) for one node; uf(t), vf(t) are the node winds"""
+    r_g, C_e, p, n, q = idc["r_g"], idc["C_e"], idc["p"], idc["n"], idc["q"]
+    e_T = math.sqrt(idc["c_e"] * idc["c_alpha"] ** (-p / q) / (idc["gamma"] * idc["c_beta"] * idc["c_D"]) ** (1 / n))
+
+    def f(t, z):
+        lne, cx, cy, x, y = z
+        u, v = uf(t), vf(t)
+        cbar = math.sqrt(cx ** 2 + cy ** 2)
+        U = math.sqrt(u ** 2 + v ** 2)
+        c_gp = abs(cbar) / r_g
+        kp = 9.81 / (4.0 * max(c_gp ** 2, 1e-2))
+        wp = 9.81 / (2.0 * max(abs(c_gp), 0.1))
+        gx, gy = cx / r_g, cy / r_g
+        alpha = min(U / (2.0 * c_gp), 500.0) if c_gp != 0 else 500.0
+        sg = math.sqrt(gx ** 2 + gy ** 2)
+        ap = (u * gx + v * gy) / (2 * max(sg, 1e-4) ** 2)
+        H = 0.5 * (1.0 + math.tanh(p * (ap - 0.85)))
+        D = 1.0 - 1.25 * (1 / math.cosh(10.0 * (ap - 0.85))) ** 2
+        It = C_e * H * alpha ** 2 if sw["input"] else 0.0
+        Dt = math.exp(n * lne) * (kp / e_T) ** (2 * n) if sw["dissipation"] else 0.0
+        Scg = C_alpha * D * kp ** 4 * math.exp(2 * lne) if sw["peak_shift"] else 0.0
+        Sd = 0.0
+        if sw["direction"]:
+            UG = U * sg
+            s2 = 0.0 if UG == 0 else (2 / UG ** 2) * (u * v * (2 * gy ** 2 - sg ** 2) - gx * gy * (2 * v ** 2 - U ** 2))
+            Sd = (min(U / (2.0 * sg), 500.0) if sg != 0 else 500.0) ** 2 * C_phi * H * s2
+        return [wp * r_g * Scg + wp * (It - Dt),
+                -cx * wp * r_g * Scg + cy * Sd,
+                -cy * wp * r_g * Scg - cx * Sd,
+                cx * inv_dx if sw["propagation"] else 0.0,
+                cy * inv_dy if sw["propagation"] else 0.0]
+    return f
+
+
+# ---------------------------------------------------------------- core_2D.jl
+def particle_to_charge(z):
+    e = math.exp(z[0])
+    c = math.sqrt(z[1] ** 2 + z[2] ** 2)
+    return np.array([e, z[1] * e / c ** 2 / 2, z[2] * e / c ** 2 / 2])
+
+
+def charge_to_particle(s):
+    e, mx, my = s
+    m = math.sqrt(mx ** 2 + my ** 2)
+    return [math.log(e), mx * e / (2 * m ** 2), my * e / (2 * m ** 2), 0.0, 0.0]
+
+
+# ---------------------------------------------------------------- ParticleInCell.jl (1-based indices, as in the reference)
+def get_absolute_i_and_w(zp, i_node):
+    b = math.floor(zp)
+    w_hi = float(np.rint((zp - b) * 1e6) / 1e6)     # Julia round(x, digits=6)
+    return (int(b) + i_node, int(b) + i_node + 1), (1.0 - w_hi, w_hi)
+
+
+def wrap_index(pos, N):
+    pos = int(math.fmod(pos, N))                   # Julia %: sign of the dividend
+    if pos <= 0:
+        pos += N
+    return pos
+
+
+def push_to_grid(S, charge, ij1, x, y, Nx, Ny, per_x, per_y):
+    xi, xw = get_absolute_i_and_w(x, ij1[0])
+    yi, yw = get_absolute_i_and_w(y, ij1[1])
+    for (i, j), (wx, wy) in zip(((xi[0], yi[0]), (xi[1], yi[0]), (xi[0], yi[1]), (xi[1], yi[1])),
+                                ((xw[0], yw[0]), (xw[1], yw[0]), (xw[0], yw[1]), (xw[1], yw[1]))):
+        if (not per_x and not (0 < i <= Nx)) or (not per_y and not (0 < j <= Ny)):
+            continue
+        S[wrap_index(i, Nx) - 1, wrap_index(j, Ny) - 1, :] += wx * wy * charge
+
+
+# ---------------------------------------------------------------- mask_utils.jl
+def make_boundaries(mask, per_x, per_y):
+    b = np.zeros(mask.shape, dtype=int)
+    for d in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+        b += (np.roll(mask, d, axis=(0, 1)) & ~mask)
+    total = mask.astype(int) + 2 * (b != 0)
+    if not per_x:
+        total[0, :] = 3
+        total[-1, :] = 3
+    if not per_y:
+        total[:, 0] = 3
+        total[:, -1] = 3
+    return total
+
+
+# ---------------------------------------------------------------- the model
+class Model:
+    def __init__(self, Nx, Ny, dx, dy, per_x, per_y, ocean, winds, periodic_boundary, C_phi, sw, DT, timestep,
+                 lne_max, wind_min_sq=4.0):
+        self.Nx, self.Ny, self.dx, self.dy, self.per_x, self.per_y = Nx, Ny, dx, dy, per_x, per_y
+        self.x = np.arange(Nx) * dx
+        self.y = np.arange(Ny) * dy
+        self.winds, self.DT, self.timestep = winds, DT, timestep
+        self.idc = id_constants()
+        self.C_alpha, self.C_phi, self.sw = -1.41, C_phi, sw
+        self.lne_max, self.wind_min_sq = lne_max, wind_min_sq
+        self.mask = make_boundaries(ocean, per_x, per_y)
+        self.periodic_boundary = periodic_boundary
+        F = lambda cls: [tuple(k) for k in np.argwhere((self.mask == cls).T)[:, ::-1]]   # findall: column-major
+        self.ocean_points = F(1) + (F(3) if periodic_boundary else [])
+        self.minimal_state = minimal_state(2, 2, timestep)
+        self.clock = 0.0
+        self.State = np.zeros((Nx, Ny, 3))
+        self.z = np.zeros((Nx, Ny, 5))
+        self.on = np.zeros((Nx, Ny), dtype=bool)
+        self.boundary = (self.mask == 2) if periodic_boundary else (self.mask >= 2)
+        self.cell = np.zeros((Nx, Ny, 2), dtype=np.int64)      # floor(x), floor(y) of the last advance
+        self.margin = np.full((Nx, Ny), np.inf)                # distance of x, y from the next integer
+        # init_particles! (run.jl:199-247) -> SeedParticle -> InitParticleValues, winds at t = 0.0
+        for j in range(Ny):
+            for i in range(Nx):
+                if self.mask[i, j] == 0:
+                    continue
+                u, v = self.wind(i, j, 0.0)
+                if math.sqrt(u ** 2 + v ** 2) > math.sqrt(2):
+                    w = get_initial_windsea(u, v, timestep)
+                    self.on[i, j] = True
+                else:
+                    w = minimal_windsea(u, v, timestep)
+                    self.on[i, j] = False
+                self.z[i, j] = [w["lne"], w["cx"], w["cy"], 0.0, 0.0]
+                if self.on[i, j]:
+                    self.State[i, j] = particle_to_charge(self.z[i, j])
+
+    def wind(self, i, j, t):
+        return float(self.winds[0](self.x[i], self.y[j], t)), float(self.winds[1](self.x[i], self.y[j], t))
+
+    def reseed(self, uv, DT):
+        w = get_initial_windsea(uv[0], uv[1], DT)
+        return [w["lne"], w["cx"], w["cy"], 0.0, 0.0]
+
+    def advance(self, i, j):
+        """advance! (mapping_2D.jl:118-243)"""
+        DT, t0 = self.DT, self.clock
+        z = list(self.z[i, j])
+        if self.on[i, j]:
+            f = make_rhs(lambda t: self.wind(i, j, t)[0], lambda t: self.wind(i, j, t)[1], self.idc, self.C_alpha,
+                         self.C_phi, 1 / self.dx, 1 / self.dy, self.sw)
+            sol = solve_ivp(f, (t0, t0 + DT), z, method="DOP853", rtol=1e-12, atol=1e-14)
+            assert sol.success
+            z = [float(a) for a in sol.y[:, -1]]
+        else:
+            w = self.wind(i, j, t0 + DT)
+            if w[0] ** 2 + w[1] ** 2 >= self.wind_min_sq:
+                z = self.reseed(w, DT)
+                self.on[i, j] = True
+        if any(math.isnan(a) for a in z[:3]):
+            z = self.reseed(self.wind(i, j, t0 + DT), DT)
+        elif any(math.isinf(a) for a in z[:3]):
+            z = self.reseed(self.wind(i, j, t0), DT)
+        elif z[0] > self.lne_max:
+            z[0] = self.lne_max
+        self.z[i, j] = z
+        if self.on[i, j]:
+            self.cell[i, j] = [math.floor(z[3]), math.floor(z[4])]
+            self.margin[i, j] = min(min(a - math.floor(a), math.floor(a) + 1 - a) for a in z[3:5])
+            push_to_grid(self.State, particle_to_charge(z), (i + 1, j + 1), z[3], z[4], self.Nx, self.Ny, self.per_x, self.per_y)
+        else:
+            self.cell[i, j] = [0, 0]
+            self.margin[i, j] = np.inf
+
+    def remesh(self, i, j):
+        """remesh! / NodeToParticle! (mapping_2D.jl:250-356); wind at model.clock.time, before tick!"""
+        u, v = self.wind(i, j, self.clock)
+        s = self.State[i, j]
+        bnd = self.boundary[i, j]
+        if (not bnd) and s[0] >= self.minimal_state[0] and (s[1] ** 2 + s[2] ** 2) >= self.minimal_state[1]:
+            self.z[i, j] = charge_to_particle(s)
+            self.on[i, j] = True
+        elif u ** 2 + v ** 2 >= self.wind_min_sq:          # branches B and C
+            self.z[i, j] = self.reseed((u, v), self.DT)
+            self.on[i, j] = True
+        else:
+            self.on[i, j] = False
+
+    def time_step(self):
+        """run!: State .= 0 (run.jl:75-79); time_step! (TimeSteppers.jl:109-166)"""
+        self.State[:] = 0.0
+        for (i, j) in self.ocean_points:
+            self.advance(i, j)
+        scattered = self.State.copy()
+        for (i, j) in self.ocean_points:
+            self.remesh(i, j)
+        self.clock += self.DT
+        return scattered
+
+
+# ---------------------------------------------------------------- the three cases
+NX, NY = 24, 20
+
+
+def ocean_mask():
+    m = np.ones((NX, NY), dtype=bool)
+    m[9:12, 8:11] = False        # land block
+    m[20, 14] = False            # single land cell
+    return m
+
+
+def winds_space(dx, dy, U=11.0, V=6.0, tfac=None):
+    Lx, Ly = NX * dx, (NY - 1) * dy
+
+    def amp(x, y):
+        # calm band: wind speed falls below 2 m/s for 0.42 Ly < y < 0.58 Ly
+        return 0.08 + np.minimum(1.0, np.abs(y / Ly - 0.5) / 0.3) ** 2
+
+    def u(x, y, t):
+        return U * amp(x, y) * (1 + 0.3 * np.sin(2 * np.pi * x / Lx)) * (1.0 if tfac is None else tfac(t))
+
+    def v(x, y, t):
+        return V * amp(x, y) * (1 + 0.4 * np.cos(2 * np.pi * x / Lx + 0.7)) * np.where(y > 0.5 * Ly, -1.0, 1.0)
+    return u, v
+
+
+ALL_ON = dict(propagation=True, input=True, dissipation=True, peak_shift=True, direction=True)
+CASES = {
+    # exact ODE (translation only): pins scatter / wrap / drop / remesh branches to rounding; reach up to 2 cells
+    "pic_only": dict(dx=300.0, dy=400.0, DT=600.0, timestep=600.0, C_phi=0.04, periodic_boundary=False, lne_max=math.log(17),
+                     sw=dict(propagation=True, input=False, dissipation=False, peak_shift=False, direction=False), tfac=None),
+    # all physics, non-stiff direction term, model periodic_boundary = true (grid-boundary particles are stepped),
+    # winds linear in time
+    "full_nonstiff": dict(dx=2000.0, dy=2500.0, DT=600.0, timestep=600.0, C_phi=1.81e-5, periodic_boundary=True,
+                          lne_max=math.log(17), sw=ALL_ON, tfac=lambda t: 1.0 + 0.3 * t / 3600.0),
+    # all physics, C_phi = c_beta = 0.04 (what the reference's scripts pass), seed time-scale != model step
+    "full_stiff": dict(dx=2000.0, dy=2500.0, DT=600.0, timestep=1800.0, C_phi=0.04, periodic_boundary=False,
+                       lne_max=math.log(27), sw=ALL_ON, tfac=None),
+}
+STEPS = (1, 3, 6)
+
+
+def main():
+    for name, c in CASES.items():
+        u, v = winds_space(c["dx"], c["dy"], tfac=c["tfac"])
+        m = Model(NX, NY, c["dx"], c["dy"], True, False, ocean_mask(), (u, v), c["periodic_boundary"], c["C_phi"], c["sw"],
+                  c["DT"], c["timestep"], c["lne_max"])
+        out = dict(state0=m.State.copy(), mask=m.mask.astype(np.int8), on0=m.on.copy(),
+                   minimal_state=np.array(m.minimal_state))
+        for k in range(1, max(STEPS) + 1):
+            S = m.time_step()
+            if k in STEPS:
+                out[f"state{k}"] = S
+                out[f"on{k}"] = m.on.copy()              # after the remesh of step k
+                out[f"cell{k}"] = m.cell.copy()          # floor(x), floor(y) after the advance of step k
+                out[f"margin{k}"] = m.margin.copy()
+                out[f"z{k}"] = m.z.copy()                # particles after the remesh of step k
+            print(name, k, "sum e", S[..., 0].sum(), "on", int(m.on.sum()), "max reach", int(np.abs(m.cell).max() + 1), flush=True)
+        np.savez_compressed(HERE / f"step2d_{name}.npz", **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""Third opinion on the whole 2D model step: oracle A (libm, literal order), oracle B (pmath, kernel order) and the
+HIP path against tests/golden/step2d_*.npz — a plain NumPy + SciPy restatement of `time_step!` written from the
+reference's Julia sources alone (tests/golden/make_step2d_fixture.py; it imports neither oracle/ nor picles_amd/),
+with `step!` replaced by the converged DOP853 solution.
+
+Stated tolerances: the (abstol 1e-4, reltol 1e-3) steppers against the converged solution stay
+within 1e-3 on `e` for C_phi = 1.81e-5 and 2e-2 for C_phi = 0.04 (half of that on c̄g); the propagation-only case
+has an exact ODE solution, so scatter / wrap / drop / remesh semantics are pinned to rounding (1e-12).
+particle -> cell indices (floor of the advanced position) must match exactly.
+"""
+import importlib.util
+import math
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from picles_amd import fetch_relations as FetchRelations
+from picles_amd.grids import TwoDCartesianGridMesh
+from picles_amd.particle_waves_v5 import ODEParameters, ODESettings, particle_equations
+from picles_amd.simulations import Simulation, initialize_simulation
+from picles_amd.timesteppers import time_step_advance, time_step_remesh
+from helpers import make_model
+
+GOLD = Path(__file__).parent / "golden"
+_spec = importlib.util.spec_from_file_location("make_step2d_fixture", GOLD / "make_step2d_fixture.py")
+GEN = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(GEN)          # case definitions only (mesh, mask, winds); its Model class is not used here
+
+# tolerance on e (relative to the node value, floored at 1e-6 of the plane maximum), on c̄g, per case
+TOL = {"pic_only": (1e-12, 1e-12), "full_nonstiff": (1e-3, 5e-4), "full_stiff": (2e-2, 1e-2)}
+BACKENDS = [("libm", 0), ("pmath", 1), pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def _cfg(name, solver):
+    c = GEN.CASES[name]
+    NX, NY = GEN.NX, GEN.NY
+    u, v = GEN.winds_space(c["dx"], c["dy"], tfac=c["tfac"])
+    grid = TwoDCartesianGridMesh(c["dx"] * (NX - 1), NX, c["dy"] * (NY - 1), NY, mask=GEN.ocean_mask(),
+                                 periodic_boundary=(True, False))
+    pars, Const_ID, Const_Scg = ODEParameters(r_g=0.85)
+    pars = dict(pars, **{"C_φ": c["C_phi"]})
+    psys = particle_equations(u, v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID, **c["sw"])
+    ws = FetchRelations.MinimalWindsea(2, 2, c["timestep"])
+    sets = ODESettings(Parameters=pars, log_energy_minimum=ws["lne"], log_energy_maximum=c["lne_max"], saving_step=c["DT"],
+                       timestep=c["timestep"], total_time=86400.0, solver=solver, dt=1e-3, dtmin=1e-4, force_dtmin=True)
+    return SimpleNamespace(
+        model=dict(grid=grid, winds=SimpleNamespace(u=u, v=v), ODEsys=psys, ODEsets=sets, ODEinit_type="wind_sea",
+                   periodic_boundary=c["periodic_boundary"], boundary_type="same", movie=False,
+                   winds_static=(c["tfac"] is None)),
+        Δt=c["DT"], n_steps=6, mode="run")
+
+
+def _rel(a, ref, floor):
+    return np.abs(a - ref) / np.maximum(np.abs(ref), floor)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name,solver", [("pic_only", "DP5"), ("full_nonstiff", "DP5"), ("full_nonstiff", "AutoTsit5"),
+                                         ("full_stiff", "DP5"), ("full_stiff", "Tsit5"), ("full_stiff", "AutoTsit5")])
+def test_whole_step_against_independent_restatement(name, solver, backend):
+    fx = np.load(GOLD / f"step2d_{name}.npz")
+    cfg = _cfg(name, solver)
+    m = make_model(cfg, backend)
+    tol_e, tol_c = TOL[name]
+    np.testing.assert_array_equal(np.asarray(m.grid.data.mask), fx["mask"])           # mask classes (mask_utils.jl)
+    np.testing.assert_allclose(m.minimal_state, fx["minimal_state"], rtol=1e-13)
+    initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    S0 = m.State
+    np.testing.assert_allclose(S0, fx["state0"], rtol=1e-12, atol=0)                   # seeds (pow: libm vs pmath)
+    _, on, _, _ = m.backend.get_particles()
+    np.testing.assert_array_equal(on.astype(bool), fx["on0"])
+    for k in range(1, 7):
+        # run!-style step through the split API so the advanced positions can be read: State .= 0, advance + scatter,
+        # [observe], remesh, tick
+        m.backend.zero_state()
+        time_step_advance(m, cfg.Δt)
+        if f"state{k}" in fx:
+            S = m.State
+            ref = fx[f"state{k}"]
+            floor = 1e-6 * np.abs(ref).max(axis=(0, 1), keepdims=True)
+            # the scattered field: energy within the stated tolerance, momenta likewise (m = c̄ e / 2|c̄|²)
+            err = _rel(S, ref, floor)
+            assert err[..., 0].max() <= tol_e, (name, solver, k, "e", err[..., 0].max())
+            assert err[..., 1:].max() <= max(tol_e, 2 * tol_c), (name, solver, k, "m", err[..., 1:].max())
+            # nodes nothing was scattered to are exactly zero in both
+            np.testing.assert_array_equal(S[..., 0] == 0.0, ref[..., 0] == 0.0)
+            # particle -> cell indices, exactly (particles within `margin` of a cell edge could legitimately land on either side)
+            z, on, _, st = m.backend.get_particles()
+            stepped = (st & 1) == 1
+            sel = stepped & on.astype(bool) & (fx[f"margin{k}"] > (1e-9 if name == "pic_only" else 5e-3))
+            assert sel.sum() > 300
+            cell = np.floor(z[..., 3:5]).astype(np.int64)
+            np.testing.assert_array_equal(cell[sel], fx[f"cell{k}"][sel])
+        time_step_remesh(m, cfg.Δt)
+        m.backend.tick(cfg.Δt)
+        m.clock.time += cfg.Δt
+        if f"on{k}" in fx:
+            z, on, _, st = m.backend.get_particles()
+            stepped = (st & 1) == 1
+            np.testing.assert_array_equal(on.astype(bool)[stepped], fx[f"on{k}"][stepped])       # remesh branches A-D
+            live = stepped & on.astype(bool)
+            zr = fx[f"z{k}"]
+            assert np.abs(z[..., 0][live] - zr[..., 0][live]).max() <= tol_e                     # ln e: absolute = relative on e
+            cmax = np.abs(zr[..., 1:3][live]).max()
+            assert np.abs(z[..., 1:3][live] - zr[..., 1:3][live]).max() <= tol_c * cmax
+
+
+def test_fixture_exercises_what_it_claims():
+    """the committed case really has wraps, drops, reach > 1, a calm band switching particles off and on, land"""
+    fx = np.load(GOLD / "step2d_pic_only.npz")
+    assert np.abs(fx["cell1"]).max() + 1 >= 2                    # reach of at least two cells
+    assert (fx["mask"] == 0).sum() >= 1 and (fx["mask"] == 2).sum() >= 4 and (fx["mask"] == 3).sum() == 2 * GEN.NX
+    assert (~fx["on0"] & (fx["mask"] == 1)).sum() > 20           # calm band: seeded off
+    assert fx["on6"].sum() > fx["on1"].sum()                     # energy spreads into the calm band: off -> on (branch A)
+    fs = np.load(GOLD / "step2d_full_stiff.npz")
+    assert (fs["on6"] != fs["on0"]).any()
