@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PICLES_ABI_VERSION 1
+#define PICLES_ABI_VERSION 2
 
 /* ---- grid: TwoDCartesianGridStatistics + mesh mask (Grids/CartesianGrid.jl:26-101,
  *      Grids/mask_utils.jl:38-55) ------------------------------------------------ */
@@ -111,7 +111,9 @@ typedef struct picles_counters {
     uint64_t halo_overflow;   /* particles that travelled beyond the scatter reach the context covers — halo_rows for a
                                  slab, 64 cells per model step for a whole-grid context — and were NOT scattered */
     int32_t  max_reach;       /* max |cell offset| any scatter corner had in the last advance */
-    int32_t  _pad;
+    int32_t  max_reach_seen;  /* the largest max_reach since picles_seed / picles_reset_counters (slab halos are sized from it) */
+    uint64_t dropped_nonfinite; /* switched-on particles whose advanced position was NaN / Inf: not scattered.  The reference
+                                 would throw in Int(floor(NaN)) (ParticleInCell.jl:58-71); here they are dropped and counted */
 } picles_counters;
 
 typedef struct picles_timing {     /* accumulated device time, ms (HIP events on the compute stream) */
@@ -225,10 +227,35 @@ int32_t picles_halo_send_dev(picles_ctx *ctx, int32_t side, void **ptr, size_t *
 int32_t picles_halo_recv_dev(picles_ctx *ctx, int32_t side, void **ptr, size_t *bytes);
 int32_t picles_halo_rows(const picles_ctx *ctx);
 int32_t picles_set_halo_rows(picles_ctx *ctx, int32_t halo_rows);  /* re-allocates records */
+/* Treat a context that owns ALL rows as a slab anyway (on = 1): the y wrap of a periodic mesh then goes through the ghost
+ * rows — filled by the halo exchange with itself, the "ring of one" — instead of being resolved locally.  Results are
+ * bit-identical; it exists so that ONE GPU can run, and check, the complete multi-GPU data path (received ghost rows are
+ * consumed by the pull).  Call before picles_seed. */
+int32_t picles_set_slab_mode(picles_ctx *ctx, int32_t on);
+
+/* ---- native slab ring: the multi-GPU model step driven from C, RCCL send/recv over xGMI -------------------
+ * One process per GPU; rank r owns slab r (rows [j_begin, j_end) of its picles_grid), neighbours r-1 / r+1, closed to a
+ * ring when the mesh is periodic in y.  RCCL is bound at run time with dlopen (no link-time dependency):
+ *   rank 0:  picles_slab_unique_id(id)  ->  the host distributes the 128 bytes (MPI_Bcast, a TCP store, a file ...)
+ *   all:     picles_slab_comm_init(ctx, id, rank, world)       ncclCommInitRank + two HIP streams
+ *   all:     picles_slab_run_steps(ctx, dt, n, flags)           n model steps, asynchronous, no host work in between:
+ *              edge rows (stream E) -> ncclGroup{Send,Send,Recv,Recv} of the halo blocks in place (stream E)
+ *              || interior rows (stream M) -> M waits for E
+ *            flags as picles_time_step (PICLES_STEP_ZERO_FIRST = run!-style = fused k_step launches)
+ *   picles_sync / picles_get_state / ... complete the last step as usual.
+ * Replaces the @threads loops of time_step! (TimeSteppers.jl:144-178) across GPUs; the reference has no distributed
+ * counterpart on this path. */
+#define PICLES_SLAB_ID_BYTES 128
+int32_t picles_slab_unique_id(void *id128);
+int32_t picles_slab_comm_init(picles_ctx *ctx, const void *id128, int32_t rank, int32_t world);
+int32_t picles_slab_run_steps(picles_ctx *ctx, double dt, int32_t n_steps, int32_t flags);
+int32_t picles_slab_exchange(picles_ctx *ctx);        /* one synchronous halo exchange of the current records (warm-up of the RCCL channels) */
+int32_t picles_slab_streams(picles_ctx *ctx, void **edge_stream, void **interior_stream);   /* hipStream_t of the ring (timing, profiling) */
+int32_t picles_slab_comm_destroy(picles_ctx *ctx);
 
 /* ---- generic particle->mesh scatter of an arbitrary particle list --------------
  * (ParticleInCell.push_to_grid! over a list, ParticleInCell.jl:341-376,530-538):
- * counting-sort into a cell list, LDS-staged grid tiles, wavefront-reduced fp64 atomics.
+ * counting-sort into a cell list, LDS-staged grid tiles (ds_add_f64 per corner), one global fp64 atomic per touched tile node.
  * ij: 2*n int32 (0-based birth node), xy: 2*n positions in cell units relative to ij,
  * charge: 3*n (e,mx,my), all SoA planes.  Adds into State. */
 int32_t picles_scatter_particles(picles_ctx *ctx, int64_t n, const int32_t *ij,

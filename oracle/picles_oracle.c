@@ -1118,7 +1118,7 @@ static inline int64_t po_wrap(int64_t i, int64_t N)
 /* returns max |cell offset| of the 4 corners (the scatter "reach") */
 static int po_particle_to_node(po_model *M, int32_t i, int32_t j, const double z[5])
 {
-    if (!(isfinite(z[3]) && isfinite(z[4]))) return 0; /* Int(floor(NaN)) would throw in Julia */
+    if (!(isfinite(z[3]) && isfinite(z[4]))) { M->cnt.dropped_nonfinite++; return 0; } /* Int(floor(NaN)) would throw in Julia */
     int64_t xi[2], yi[2];
     double xw[2], yw[2], c[3];
     po_index_weight(z[3], i, xi, xw);
@@ -1429,6 +1429,7 @@ PO_EXPORT int32_t picles_oracle_advance(po_model *M, double DT)
         if (r > reach) reach = r;
     }
     M->cnt.max_reach = reach;
+    if (reach > M->cnt.max_reach_seen) M->cnt.max_reach_seen = reach;
     return 0;
 }
 
@@ -1553,6 +1554,7 @@ static void po_write_record(po_model *M, int64_t idx, int *reach_out, int *overf
         if (r > *reach_out) *reach_out = r;
         if (!M->single_slab && r > M->R) (*overflow)++;
     }
+    else if (M->on[idx]) M->cnt.dropped_nonfinite++;
     rr[5 * M->Nx + i] = flag;
 }
 
@@ -1592,6 +1594,7 @@ PO_EXPORT int32_t picles_oracle_advance_rows(po_model *M, int32_t which)
     M->cnt.particles_advanced += adv;
     M->cnt.halo_overflow += overflow;
     if (reach > M->cnt.max_reach) M->cnt.max_reach = reach;
+    if (reach > M->cnt.max_reach_seen) M->cnt.max_reach_seen = reach;
     return 0;
 }
 

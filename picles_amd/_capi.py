@@ -66,7 +66,8 @@ class PiclesCounters(C.Structure):
         ("rhs_evals", C.c_uint64), ("steps_accepted", C.c_uint64), ("steps_rejected", C.c_uint64),
         ("reseeds", C.c_uint64), ("clamps", C.c_uint64), ("maxiters_hits", C.c_uint64),
         ("particles_advanced", C.c_uint64), ("halo_overflow", C.c_uint64),
-        ("max_reach", C.c_int32), ("_pad", C.c_int32),
+        ("max_reach", C.c_int32), ("max_reach_seen", C.c_int32),
+        ("dropped_nonfinite", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -88,6 +89,8 @@ class PiclesTiming(C.Structure):
 STEP_ZERO_FIRST = 1
 STEP_MOVIE = 2
 STEP_ATOMIC = 4
+ABI_VERSION = 2
+SLAB_ID_BYTES = 128
 
 ROWS_ALL, ROWS_EDGE, ROWS_INTERIOR = 0, 1, 2
 
@@ -139,6 +142,13 @@ SYMBOLS = {
     "picles_halo_recv_dev": (C.c_int32, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_size_t)]),
     "picles_halo_rows": (C.c_int32, [_VP]),
     "picles_set_halo_rows": (C.c_int32, [_VP, C.c_int32]),
+    "picles_set_slab_mode": (C.c_int32, [_VP, C.c_int32]),
+    "picles_slab_unique_id": (C.c_int32, [_VP]),
+    "picles_slab_comm_init": (C.c_int32, [_VP, _VP, C.c_int32, C.c_int32]),
+    "picles_slab_run_steps": (C.c_int32, [_VP, C.c_double, C.c_int32, C.c_int32]),
+    "picles_slab_exchange": (C.c_int32, [_VP]),
+    "picles_slab_streams": (C.c_int32, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
+    "picles_slab_comm_destroy": (C.c_int32, [_VP]),
     "picles_scatter_particles": (C.c_int32, [_VP, C.c_int64, c_int32_p, c_double_p, c_double_p]),
 }
 
@@ -165,6 +175,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    if lib.picles_abi_version() != ABI_VERSION:
+        raise PiclesError(f"{p}: ABI version {lib.picles_abi_version()}, this binding expects {ABI_VERSION} — rebuild the library")
     if path is None:
         _lib = lib
     return lib

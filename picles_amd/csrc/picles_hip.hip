@@ -64,6 +64,7 @@ struct GridP {
 #define NSLOTS 1024
 struct DevCounters {
     unsigned long long rhs, acc, rej, reseeds, clamps, maxit, adv, overflow;
+    unsigned long long nonfinite, pad_[7];     /* two 64-B lines per slot */
 };
 
 struct Arrays {
@@ -81,6 +82,7 @@ struct Arrays {
     DevCounters *cnt;        /* [NSLOTS] */
     int *max_reach;          /* max scatter reach of the records in `rec` (read by the pull) */
     int *max_reach_out;      /* ... of the records being written to `rec_out` */
+    int *max_reach_total;    /* running maximum since the last reset (slab halos are sized from it) */
     long long n;             /* Nx * ny_loc */
 };
 
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, cons
  * ---------------------------------------------------------------------------------------- */
 struct StepStats {
     PStats st;
-    unsigned int adv, reseeds, clamps, maxit, overflow;
+    unsigned int adv, reseeds, clamps, maxit, overflow, nonfinite;
     int reach;
 };
 
@@ -253,9 +255,11 @@ __device__ __forceinline__ void write_record(const GridP &G, const Arrays &A, in
 {
     double *rr = rec_row_out(A, G, jl + G.R);
     double code = 0.0;
-    if (on && pm_isfinite(z.x) && pm_isfinite(z.y) && !(pm_fabs(z.x) < 2047.0 && pm_fabs(z.y) < 2047.0)) {
+    if (on && !(pm_isfinite(z.x) && pm_isfinite(z.y))) {
+        S.nonfinite = 1;         /* the reference would throw in Int(floor(NaN)) (ParticleInCell.jl:58-71): dropped and counted */
+    } else if (on && !(pm_fabs(z.x) < 2047.0 && pm_fabs(z.y) < 2047.0)) {
         S.overflow = 1;          /* farther than the record code can hold (and than any int conversion should see) */
-    } else if (on && pm_isfinite(z.x) && pm_isfinite(z.y)) {
+    } else if (on) {
         double e, mx, my;
         particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
         int bx, by;
@@ -283,6 +287,7 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
     unsigned long long s_ar = wave_sum_u64(((unsigned long long)S.st.acc << 32) | S.st.rej);
     unsigned long long b_adv = __ballot(S.adv != 0), b_res1 = __ballot(S.reseeds == 1), b_res2 = __ballot(S.reseeds >= 2);
     unsigned long long b_cl = __ballot(S.clamps != 0), b_mx = __ballot(S.maxit != 0), b_ov = __ballot(S.overflow != 0);
+    unsigned long long b_nf = __ballot(S.nonfinite != 0);
     int m_reach = 0;
     if (__ballot(S.reach > 0)) {
         m_reach = 1;
@@ -300,9 +305,12 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
         if (b_cl) atomicAdd(&c->clamps, (unsigned long long)__popcll(b_cl));
         if (b_mx) atomicAdd(&c->maxit, (unsigned long long)__popcll(b_mx));
         if (b_ov) atomicAdd(&c->overflow, (unsigned long long)__popcll(b_ov));
+        if (b_nf) atomicAdd(&c->nonfinite, (unsigned long long)__popcll(b_nf));
         /* one address for the whole grid: only waves that would raise it touch it */
         if (m_reach > __hip_atomic_load(A.max_reach_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(A.max_reach_out, m_reach);
+        if (m_reach > __hip_atomic_load(A.max_reach_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(A.max_reach_total, m_reach);
     }
 }
 
@@ -344,7 +352,7 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
     bool active = rows_index(G, r0, n0, r1, n1, t);
     unsigned char pf = active ? A.pflags[t] : 0;
     active = active && (pf & PF_STEPPED);
-    StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0};
+    StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0u, 0};
     if (active) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
         Vec5 z;
@@ -687,7 +695,7 @@ __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, 
     pm_device_init();
     long long t = 0;
     bool active = rows_index(G, r0, n0, r1, n1, t);
-    StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0};
+    StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0u, 0};
     if (active) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -923,8 +931,12 @@ struct picles_ctx {
     int device;
     hipStream_t stream;
     hipEvent_t ev_edge;
+    hipEvent_t ev_ctx = nullptr;        /* "everything enqueued on the context stream so far": caller streams wait for it */
+    hipEvent_t ev_prologue = nullptr;   /* the per-step clear of the reach counter, recorded on the step's first stream */
+    hipStream_t prologue_stream = nullptr;
     bool edge_pending = false;
     bool step_fresh = false;
+    struct SlabRing *ring = nullptr;    /* native RCCL slab ring (picles_slab_*) */
     /* record buffer pair: rec_buf[cur] belongs to the step in flight / last completed advance */
     double *rec_buf[2] = {nullptr, nullptr};
     int *mr_buf[2] = {nullptr, nullptr};
@@ -960,6 +972,7 @@ struct picles_ctx {
     double wind_t1 = 0.0;          /* time level currently held in (u1, v1) */
     bool wind_t1_valid = false;
     bool ext_streams = false;      /* a caller-provided stream has been used: order across streams with device syncs */
+    bool ring_orders = false;      /* inside picles_slab_run_steps: the ring orders its streams against the context stream with events */
     /* generic scatter scratch */
     int *d_count = nullptr, *d_start = nullptr, *d_cursor = nullptr;
     void *d_scan_tmp = nullptr;
@@ -1052,6 +1065,7 @@ PX_EXPORT const char *picles_last_error(const picles_ctx *ctx)
 }
 
 PX_EXPORT int32_t picles_destroy(picles_ctx *c);
+PX_EXPORT int32_t picles_slab_comm_destroy(picles_ctx *c);
 
 PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, const picles_ode *o,
                                 const picles_model *m, int32_t device_id, int32_t halo_rows, picles_ctx **out)
@@ -1167,6 +1181,8 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
 #define CK(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e2); picles_destroy(c); return -10; } } while (0)
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&c->ev_ctx, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&c->ev_prologue, hipEventDisableTiming));
     Arrays &A = c->A;
     memset(&A, 0, sizeof(A));
     A.n = n;
@@ -1176,6 +1192,8 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     CK(hipMalloc(&A.on, n)); CK(hipMalloc(&A.pflags, n)); CK(hipMalloc(&A.status, n * 4));
     CK(hipMalloc(&A.u0, n * 8)); CK(hipMalloc(&A.v0, n * 8)); CK(hipMalloc(&A.u1, n * 8)); CK(hipMalloc(&A.v1, n * 8));
     CK(hipMalloc(&A.cnt, NSLOTS * sizeof(DevCounters)));
+    CK(hipMalloc(&A.max_reach_total, sizeof(int)));
+    CK(hipMemset(A.max_reach_total, 0, sizeof(int)));
     for (int k = 0; k < 2; k++) {
         CK(hipMalloc(&c->mr_buf[k], sizeof(int)));
         CK(hipMemset(c->mr_buf[k], 0, sizeof(int)));
@@ -1199,12 +1217,13 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
 {
     if (!c) return 0;
     hipSetDevice(c->device);
+    if (c->ring) picles_slab_comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     Arrays &A = c->A;
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.asw); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
-    hipFree(A.cnt); hipFree(c->d_mask);
+    hipFree(A.cnt); hipFree(A.max_reach_total); hipFree(c->d_mask);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
     for (int k = 0; k < 2; k++) { hipFree(c->rec_buf[k]); hipFree(c->mr_buf[k]); }
     for (auto p : c->store_dev) hipFree(p);
@@ -1221,6 +1240,8 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     for (auto &e : c->ev_used) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto &e : c->ev_free) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (c->ev_edge) hipEventDestroy(c->ev_edge);
+    if (c->ev_ctx) hipEventDestroy(c->ev_ctx);
+    if (c->ev_prologue) hipEventDestroy(c->ev_prologue);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1360,6 +1381,7 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
         HIPCHK(c, hipMemsetAsync(c->mr_buf[k], 0, sizeof(int), c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->A.max_reach_total, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, arrays_for(c, 0, 0), c->d_mask, c->od.timestep);
     HIPCHK(c, hipGetLastError());
     c->state_zero = false;
@@ -1396,10 +1418,10 @@ PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
     c->step_fresh = true;   /* the first advance_rows of the step clears max_reach on ITS stream */
     if (c->wind_grid_on) {
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipDeviceSynchronize());   /* previous step (any stream) done with the wind planes */
+        if (c->ext_streams && !c->ring_orders) HIPCHK(c, hipDeviceSynchronize());   /* previous step (any stream) done with the wind planes */
         int rc = wind_grid_prepare(c, c->clock, dt, c->stream);
         if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        /* caller-stream launches wait for the sampler through ev_ctx (step_prologue) */
     }
     return 0;
 }
@@ -1420,12 +1442,25 @@ static int select_rows(picles_ctx *c, int which, int &r0, int &n0, int &r1, int 
     return 0;
 }
 
-/* first launch of a step on stream s: clear the per-step reach counter there */
+/* Launches of one step may come on caller-provided streams.  Two orderings are the library's business:
+ *  - whatever it enqueued on its own stream before (the scatter + remesh of a flushed step, a wind-lattice
+ *    sample, the seed) must be complete before a caller-stream kernel reads it: the caller stream waits for an
+ *    event recorded on the context stream;
+ *  - the first launch of a step clears the step's reach counter on ITS stream; a launch of the same step on
+ *    another stream waits for that clear (its atomicMax must not land before it). */
 static int step_prologue(picles_ctx *c, hipStream_t s)
 {
+    if (s != c->stream) {
+        HIPCHK(c, hipEventRecord(c->ev_ctx, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_ctx, 0));
+    }
     if (c->step_fresh) {
         HIPCHK(c, hipMemsetAsync(c->mr_buf[c->cur], 0, sizeof(int), s));
+        HIPCHK(c, hipEventRecord(c->ev_prologue, s));
+        c->prologue_stream = s;
         c->step_fresh = false;
+    } else if (s != c->prologue_stream) {
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_prologue, 0));
     }
     return 0;
 }
@@ -1552,7 +1587,8 @@ PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
         Arrays &A = c->A;
         if (c->pending && !(c->wind_t1_valid && c->wind_t1 == c->clock && c->P.tw0 == c->pend_t && !c->P.wind_static))
             return 1;   /* the windows are not contiguous: take the plain phases (they flush first) */
-        if (c->ext_streams) HIPCHK(c, hipDeviceSynchronize());   /* earlier launches on other streams read the planes */
+        /* earlier launches on other streams read the planes (the native slab ring orders its own streams with events) */
+        if (c->ext_streams && !c->ring_orders) HIPCHK(c, hipDeviceSynchronize());
         if (c->pending) {
             if (!A.uP) {
                 HIPCHK(c, hipMalloc(&A.uP, (size_t)A.n * 8));
@@ -1572,7 +1608,7 @@ PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
             int rc = wind_grid_prepare(c, c->clock, dt, c->stream);
             if (rc) return rc;
         }
-        if (c->ext_streams) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->ext_streams && !c->ring_orders) HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->step_dt = dt;
     c->step_flags = PICLES_STEP_ZERO_FIRST;
@@ -1650,6 +1686,10 @@ PX_EXPORT int32_t picles_scatter_remesh(picles_ctx *c, void *stream)
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (c->edge_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_edge, 0)); c->edge_pending = false; }
+    if (s != c->stream) {   /* ordered behind whatever the library enqueued on its own stream (see step_prologue) */
+        HIPCHK(c, hipEventRecord(c->ev_ctx, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_ctx, 0));
+    }
     int rc = launch_scatter(c, s, true);
     if (rc) return rc;
     c->clock += c->step_dt;
@@ -1769,15 +1809,18 @@ PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
     std::vector<DevCounters> d(NSLOTS);
     int rc = d2h(c, d.data(), c->A.cnt, NSLOTS * sizeof(DevCounters));
     if (rc) return rc;
-    int mr = 0;
+    int mr = 0, mrt = 0;
     if ((rc = d2h(c, &mr, c->mr_buf[c->cur], sizeof(int)))) return rc;
+    if ((rc = d2h(c, &mrt, c->A.max_reach_total, sizeof(int)))) return rc;
     memset(out, 0, sizeof(*out));
     for (const DevCounters &k : d) {
         out->rhs_evals += k.rhs; out->steps_accepted += k.acc; out->steps_rejected += k.rej;
         out->reseeds += k.reseeds; out->clamps += k.clamps; out->maxiters_hits += k.maxit;
         out->particles_advanced += k.adv; out->halo_overflow += k.overflow;
+        out->dropped_nonfinite += k.nonfinite;
     }
     out->max_reach = mr;
+    out->max_reach_seen = mrt;
     return 0;
 }
 
@@ -1788,6 +1831,7 @@ PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
     { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->A.max_reach_total, 0, sizeof(int), c->stream));
     return 0;
 }
 
@@ -1901,6 +1945,25 @@ PX_EXPORT int32_t picles_set_halo_rows(picles_ctx *c, int32_t r)
     return 0;
 }
 
+PX_EXPORT int32_t picles_set_slab_mode(picles_ctx *c, int32_t on)
+{
+    if (!c) return -1;
+    GridP &G = c->G;
+    if (!(G.j_begin == 0 && G.ny_loc == G.Ny)) return on ? 0 : fail(c, -2, "a partial slab cannot resolve the y wrap locally");
+    if (c->pending || c->seeded) return fail(c, -2, "picles_set_slab_mode: call before picles_seed");
+    if (on) {
+        if ((G.periodic_y && G.Ny <= 2 * G.R) || G.ny_loc < G.R)
+            return fail(c, -2, "slab: periodic y axis not longer than 2*halo_rows, or fewer own rows than halo_rows");
+        if (G.tripolar) return fail(c, -5, "slab mode on a whole tripolar grid is not supported");
+        G.single_slab = 0;
+        G.Rp = G.R;
+    } else {
+        G.single_slab = 1;
+        G.Rp = 0;
+    }
+    return 0;
+}
+
 static int halo_ptr(picles_ctx *c, int side, bool send, void **ptr, size_t *bytes)
 {
     if (!c || !ptr || !bytes || side < 0 || side > 1) return -1;
@@ -1916,6 +1979,217 @@ static int halo_ptr(picles_ctx *c, int side, bool send, void **ptr, size_t *byte
 }
 PX_EXPORT int32_t picles_halo_send_dev(picles_ctx *c, int32_t side, void **ptr, size_t *bytes) { return halo_ptr(c, side, true, ptr, bytes); }
 PX_EXPORT int32_t picles_halo_recv_dev(picles_ctx *c, int32_t side, void **ptr, size_t *bytes) { return halo_ptr(c, side, false, ptr, bytes); }
+
+/* ------------------------------------------------------------------------------------------
+ * Native slab ring: the multi-GPU model step with no interpreter in the loop.
+ * RCCL is bound at run time (dlopen of librccl.so.1 — the copy already in the process if the host has
+ * loaded one, e.g. PyTorch's): the library has no link-time dependency on it and single-GPU hosts never
+ * touch it.  One communicator per context = per GPU = per process; rank r owns slab r of a y-ring.
+ * Per model step:
+ *     edge rows   k_step on stream E  ->  ncclGroup{Send hi->next, Send lo->prev, Recv lo<-prev, Recv hi<-next} on E
+ *     interior    k_step on stream M      (overlaps the exchange)
+ *     M waits for E (the halo has landed before the next step's launches pull from it)
+ * The halo blocks are contiguous row ranges of the record buffer: sent and received in place.
+ * The reference has no counterpart (TimeSteppers.jl:144-178 is a shared-memory @threads loop).
+ * ---------------------------------------------------------------------------------------- */
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    void *handle = nullptr;
+};
+
+static RcclApi *rccl_api(std::string &err)
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (api.handle) return &api;
+    if (tried) { err = "RCCL could not be loaded"; return nullptr; }
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;    /* the copy already loaded, if any */
+    if (!h) for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { err = std::string("dlopen(librccl.so.1): ") + dlerror(); return nullptr; }
+#define RSYM(f) do { api.f = (decltype(api.f))dlsym(h, "nccl" #f); if (!api.f) { err = "librccl lacks nccl" #f; return nullptr; } } while (0)
+    RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(CommDestroy); RSYM(GroupStart); RSYM(GroupEnd); RSYM(Send); RSYM(Recv);
+    RSYM(GetErrorString);
+#undef RSYM
+    api.handle = h;
+    return &api;
+}
+
+struct SlabRing {
+    RcclApi *api = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, prev = -1, next = -1;      /* -1: no neighbour on that side (open y axis) */
+    hipStream_t sE = nullptr, sM = nullptr;
+    hipEvent_t evE = nullptr, evM = nullptr;
+    unsigned long long steps = 0, exchanged_bytes = 0;
+};
+
+#define NCCLCHK(c, R, call)                                                                     \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess) {                                                                \
+            (c)->err = std::string(#call) + ": " + (R)->api->GetErrorString(r_);                \
+            return -11;                                                                         \
+        }                                                                                       \
+    } while (0)
+
+PX_EXPORT int32_t picles_slab_unique_id(void *id128)
+{
+    if (!id128) return -1;
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) { g_create_error = err; return -11; }
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + api->GetErrorString(r); return -11; }
+    static_assert(sizeof(id) == PICLES_SLAB_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+PX_EXPORT int32_t picles_slab_comm_destroy(picles_ctx *c)
+{
+    if (!c) return -1;
+    SlabRing *R = c->ring;
+    if (!R) return 0;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    if (R->comm) R->api->CommDestroy(R->comm);
+    if (R->evE) hipEventDestroy(R->evE);
+    if (R->evM) hipEventDestroy(R->evM);
+    if (R->sE) hipStreamDestroy(R->sE);
+    if (R->sM) hipStreamDestroy(R->sM);
+    delete R;
+    c->ring = nullptr;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_slab_comm_init(picles_ctx *c, const void *id128, int32_t rank, int32_t world)
+{
+    if (!c || !id128) return -1;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, -2, "slab ring: need 0 <= rank < world");
+    if (c->ring) return fail(c, -2, "slab ring already initialised");
+    if (c->G.single_slab && world > 1) return fail(c, -2, "slab ring of several ranks needs slab contexts (j_begin, j_end)");
+    if (c->G.tripolar) return fail(c, -5, "slab ring: the tripolar fold is not wired into the native ring (use picles_amd.parallel)");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(c, -11, err);
+    SlabRing *R = new SlabRing();
+    R->api = api; R->rank = rank; R->world = world;
+    const bool per = c->G.periodic_y;
+    R->prev = (rank > 0) ? rank - 1 : (per ? world - 1 : -1);
+    R->next = (rank < world - 1) ? rank + 1 : (per ? 0 : -1);
+    if (c->G.single_slab) R->prev = R->next = -1;       /* a whole-grid context wraps locally: nothing to exchange */
+    c->ring = R;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = api->CommInitRank(&R->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        c->err = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
+        R->comm = nullptr;
+        picles_slab_comm_destroy(c);
+        return -11;
+    }
+    HIPCHK(c, hipStreamCreateWithFlags(&R->sE, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&R->sM, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&R->evE, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&R->evM, hipEventDisableTiming));
+    return 0;
+}
+
+/* the halo exchange of the step in flight, in place, on stream s */
+static int ring_exchange(picles_ctx *c, SlabRing *R, hipStream_t s)
+{
+    if (R->prev < 0 && R->next < 0) return 0;
+    void *s_lo, *s_hi, *r_lo, *r_hi;
+    size_t b = 0;
+    int rc;
+    if ((rc = halo_ptr(c, 0, true, &s_lo, &b)) || (rc = halo_ptr(c, 1, true, &s_hi, &b)) ||
+        (rc = halo_ptr(c, 0, false, &r_lo, &b)) || (rc = halo_ptr(c, 1, false, &r_hi, &b))) return rc;
+    const size_t n = b / 8;
+    /* order matters when prev == next (two ranks on a periodic axis, or the ring of one): sends [hi -> next, lo -> prev]
+     * pair with the peer's recvs [lo <- prev, hi <- next] */
+    NCCLCHK(c, R, R->api->GroupStart());
+    if (R->next >= 0) NCCLCHK(c, R, R->api->Send(s_hi, n, ncclDouble, R->next, R->comm, s));
+    if (R->prev >= 0) NCCLCHK(c, R, R->api->Send(s_lo, n, ncclDouble, R->prev, R->comm, s));
+    if (R->prev >= 0) NCCLCHK(c, R, R->api->Recv(r_lo, n, ncclDouble, R->prev, R->comm, s));
+    if (R->next >= 0) NCCLCHK(c, R, R->api->Recv(r_hi, n, ncclDouble, R->next, R->comm, s));
+    NCCLCHK(c, R, R->api->GroupEnd());
+    R->exchanged_bytes += (size_t)((R->next >= 0) + (R->prev >= 0)) * b;
+    return 0;
+}
+
+PX_EXPORT int32_t picles_slab_exchange(picles_ctx *c)
+{
+    if (!c) return -1;
+    SlabRing *R = c->ring;
+    if (!R) return fail(c, -2, "picles_slab_comm_init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    int rc = ring_exchange(c, R, R->sE);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(R->sE));
+    return 0;
+}
+
+PX_EXPORT int32_t picles_slab_run_steps(picles_ctx *c, double dt, int32_t n_steps, int32_t flags)
+{
+    if (!c || n_steps < 0) return -1;
+    SlabRing *R = c->ring;
+    if (!R) return fail(c, -2, "picles_slab_comm_init first");
+    if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
+    if (flags & PICLES_STEP_ATOMIC) return fail(c, -5, "PICLES_STEP_ATOMIC is single-slab only");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->ext_streams = true;
+    c->ring_orders = true;
+    struct Off { picles_ctx *c; ~Off() { c->ring_orders = false; } } off{c};
+    for (int k = 0; k < n_steps; k++) {
+        /* the context stream (wind-lattice sampler of this step, a flushed scatter) must come after the previous
+         * step's launches on E and M, and this step's launches after it (step_prologue: ev_ctx) */
+        HIPCHK(c, hipEventRecord(R->evM, R->sM));
+        HIPCHK(c, hipEventRecord(R->evE, R->sE));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, R->evM, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, R->evE, 0));
+        int fused = (flags == PICLES_STEP_ZERO_FIRST) ? picles_begin_fused_step(c, dt) : 1;
+        if (fused < 0) return fused;
+        if (fused == 1) { int rc = picles_begin_step(c, dt, flags); if (rc) return rc; }
+        /* the previous step's interior launch (stream M) wrote / read what the edge launch touches */
+        HIPCHK(c, hipStreamWaitEvent(R->sE, R->evM, 0));
+        int rc = (fused == 0) ? picles_step_rows(c, PICLES_ROWS_EDGE, R->sE) : picles_advance_rows(c, PICLES_ROWS_EDGE, R->sE);
+        if (rc) return rc;
+        if ((rc = ring_exchange(c, R, R->sE))) return rc;
+        rc = (fused == 0) ? picles_step_rows(c, PICLES_ROWS_INTERIOR, R->sM) : picles_advance_rows(c, PICLES_ROWS_INTERIOR, R->sM);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(R->evE, R->sE));
+        HIPCHK(c, hipStreamWaitEvent(R->sM, R->evE, 0));      /* stream M waits for the edge rows and the halo */
+        c->edge_pending = false;
+        rc = (fused == 0) ? picles_end_fused_step(c) : picles_scatter_remesh(c, R->sM);
+        if (rc) return rc;
+        R->steps++;
+    }
+    return 0;
+}
+
+PX_EXPORT int32_t picles_slab_streams(picles_ctx *c, void **edge, void **interior)
+{
+    if (!c || !c->ring) return -1;
+    if (edge) *edge = c->ring->sE;
+    if (interior) *interior = c->ring->sM;
+    return 0;
+}
 
 /* ---- generic push_to_grid! of a particle list ---- */
 PX_EXPORT int32_t picles_scatter_particles(picles_ctx *c, int64_t np, const int32_t *ij, const double *xy, const double *charge)

@@ -157,6 +157,38 @@ class HipModel:
     def set_halo_rows(self, r):
         self._ck(self.lib.picles_set_halo_rows(self.h, r), "picles_set_halo_rows")
 
+    def set_slab_mode(self, on=True):
+        """a whole-grid context behaves as a slab: the periodic y wrap goes through the ghost rows (ring of one)"""
+        self._ck(self.lib.picles_set_slab_mode(self.h, int(on)), "picles_set_slab_mode")
+
+    # ---- native slab ring (RCCL send/recv driven from C) ----
+    def slab_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(K.SLAB_ID_BYTES)
+        rc = self.lib.picles_slab_unique_id(buf)
+        if rc != 0:
+            msg = self.lib.picles_last_error(None)
+            raise K.PiclesError(f"picles_slab_unique_id failed (rc={rc}): {msg.decode() if msg else '?'}")
+        return buf.raw
+
+    def slab_comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == K.SLAB_ID_BYTES
+        buf = C.create_string_buffer(unique_id, K.SLAB_ID_BYTES)
+        self._ck(self.lib.picles_slab_comm_init(self.h, buf, rank, world), "picles_slab_comm_init")
+
+    def slab_run_steps(self, dt, n, flags=K.STEP_ZERO_FIRST):
+        self._ck(self.lib.picles_slab_run_steps(self.h, dt, n, flags), "picles_slab_run_steps")
+
+    def slab_exchange(self):
+        self._ck(self.lib.picles_slab_exchange(self.h), "picles_slab_exchange")
+
+    def slab_streams(self):
+        e, m = C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.picles_slab_streams(self.h, C.byref(e), C.byref(m)), "picles_slab_streams")
+        return e.value, m.value
+
+    def slab_comm_destroy(self):
+        self._ck(self.lib.picles_slab_comm_destroy(self.h), "picles_slab_comm_destroy")
+
     # ---- outputs ----
     def get_state(self):
         s = np.empty(3 * self.N)

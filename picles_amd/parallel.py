@@ -118,9 +118,6 @@ class HaloExchange:
         ops = []
         # order matters when prev == next (2 ranks, periodic): sends [hi->next, lo->prev],
         # recvs [lo<-prev, hi<-next] pair up correctly on both sides
-        if getattr(self, "_fail_next_inplace", False) and not self.staged:    # test hook: see SlabModel.seed
-            self._fail_next_inplace = False
-            raise RuntimeError("injected failure of the in-place halo exchange")
         g = self.group
         if self.next is not None:
             ops.append(dist.P2POp(dist.isend, T["send_hi"], self.next, group=g))
@@ -150,7 +147,7 @@ class SlabModel:
 
     def __init__(self, cfg_model: dict, rank: int, world: int, device: int = 0, halo_rows: int = 1,
                  backend_factory=None, use_streams=True, exchange=None, auto_halo_every: int = 0, fallback_group=None,
-                 ring_of_one=False):
+                 ring_of_one=False, native_ring=None, consume_ghost_rows=True):
         from . import fetch_relations as FetchRelations
         grid, ODEsys, ODEsets = cfg_model["grid"], cfg_model["ODEsys"], cfg_model["ODEsets"]
         self.grid, self.winds = grid, cfg_model["winds"]
@@ -186,7 +183,23 @@ class SlabModel:
         self.n_stepped = self._count_stepped()
         ring_of_one = bool(ring_of_one) and world == 1 and self.periodic_y
         self.use_streams = use_streams and (world > 1 or ring_of_one) and backend_factory is None
-        if exchange is not None:          # caller-supplied exchange object (start() / finish(works)), e.g. several slabs in one process
+        if ring_of_one and consume_ghost_rows and hasattr(self.backend, "set_slab_mode"):
+            # the whole-grid context becomes a slab: its periodic y wrap goes through the ghost rows the ring of one
+            # receives from itself, so the pull CONSUMES what the transport delivered (bit-identical to the local wrap)
+            self.backend.set_slab_mode(True)
+        # native ring: the whole step loop lives in libpicles_hip.so (picles_slab_run_steps: RCCL send/recv issued from
+        # C on the library's own streams); torch.distributed only carries the 128-byte ncclUniqueId.  Default whenever
+        # the transport is RCCL and nothing asks for the Python-driven exchange.
+        self.native = False
+        if native_ring is None:
+            native_ring = (exchange is None and backend_factory is None and use_streams and (world > 1 or ring_of_one)
+                           and (ring_of_one or self._dist_backend() == "nccl"))
+        if native_ring:
+            self._init_native_ring(rank, world)
+        if self.native:
+            self.ex = None
+            self.use_streams = False
+        elif exchange is not None:          # caller-supplied exchange object (start() / finish(works)), e.g. several slabs in one process
             self.ex = exchange
             self.use_streams = False
         else:
@@ -197,6 +210,45 @@ class SlabModel:
             import torch
             self.s_edge = torch.cuda.Stream()
             self.s_main = torch.cuda.Stream()
+
+    @staticmethod
+    def _dist_backend():
+        try:
+            import torch.distributed as dist
+            return dist.get_backend() if dist.is_initialized() else "none"
+        except Exception:
+            return "none"
+
+    def _init_native_ring(self, rank, world):
+        """rank 0 draws the ncclUniqueId, torch.distributed broadcasts the 128 bytes, every rank joins the ring"""
+        import sys
+        b = self.backend
+        try:
+            uid = b.slab_unique_id() if rank == 0 else None
+            if world > 1:
+                import torch.distributed as dist
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            b.slab_comm_init(uid, rank, world)
+            self.native = True
+        except K.PiclesError as e:
+            if world > 1:
+                import torch.distributed as dist
+                # every rank must agree on the transport: a failure anywhere falls back everywhere
+                print(f"[picles_amd] rank {rank}: native slab ring unavailable ({e}); using the torch.distributed exchange",
+                      file=sys.stderr, flush=True)
+            else:
+                raise
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            ok = torch.tensor([1 if self.native else 0], dtype=torch.int32,
+                              device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0 and self.native:
+                b.slab_comm_destroy()
+                self.native = False
 
     def _count_stepped(self):
         mk = self.grid.data.mask[:, self.j0:self.j1]
@@ -231,6 +283,11 @@ class SlabModel:
         self.upload_winds(0.0, self.timestep)
         self.backend.seed(0.0)
         self.backend.sync()        # the seed kernel runs on the context stream, the steps on s_edge / s_main
+        if self.native and not getattr(self, "_comm_warm", False):
+            self.backend.slab_exchange()     # RCCL builds its P2P channels on first use: keep that out of the first step
+            self._comm_warm = True
+            self.backend.seed(0.0)           # restore the zero ghost rows the throw-away exchange touched
+            self.backend.sync()
         if self.ex is not None and not getattr(self, "_comm_warm", False):
             # one throw-away exchange: RCCL builds its P2P channels lazily on first use — keep that
             # out of the first model step (the ghost rows are rewritten by every real exchange)
@@ -262,7 +319,9 @@ class SlabModel:
     def time_step(self, dt, flags=K.STEP_ZERO_FIRST):
         self.upload_winds(self.clock, dt)
         b = self.backend
-        if self.ex is None:
+        if self.native:
+            b.slab_run_steps(dt, 1, flags)
+        elif self.ex is None:
             b.time_step(dt, flags)
         elif self.use_streams:
             torch = self.ex.torch
@@ -294,6 +353,28 @@ class SlabModel:
         if self.auto_halo_every > 0 and self.world > 1 and self._steps_done % self.auto_halo_every == 0:
             self.grow_halo_if_needed()
 
+    def run_steps(self, dt, n, flags=K.STEP_ZERO_FIRST):
+        """n consecutive model steps; with the native ring and winds the device can produce by itself (static, or a
+        device-resident lattice) this is ONE call into the library — no interpreter between the steps"""
+        from .wind_emulator import GriddedWinds
+        hands_off = self.native and (self.static or isinstance(self.winds, GriddedWinds)) and self.auto_halo_every <= 0
+        if not hands_off:
+            for _ in range(n):
+                self.time_step(dt, flags)
+            return
+        self.upload_winds(self.clock, dt)
+        self.backend.slab_run_steps(dt, n, flags)
+        self.clock += n * dt
+        self._steps_done += n
+
+    def check_overflow(self):
+        """raise if any particle travelled beyond the ghost rows (it was not scattered: the State is incomplete)"""
+        c = self.backend.get_counters()
+        if c["halo_overflow"] or c.get("dropped_nonfinite", 0):
+            raise K.PiclesError(f"rank {self.rank}: {c['halo_overflow']} particles travelled beyond halo_rows = "
+                                f"{self.backend.halo_rows} (max reach seen {c.get('max_reach_seen')}), {c.get('dropped_nonfinite', 0)} "
+                                "had a non-finite position; they were not scattered")
+
     def grow_halo_if_needed(self):
         """collective: if any rank's scatter reach has reached halo_rows, every rank adds one ghost row.
         The reach of a developing sea grows by a fraction of a cell per model step, so checking every few
@@ -301,9 +382,11 @@ class SlabModel:
         import torch
         import torch.distributed as dist
         self.sync()
-        reach = torch.tensor([float(self.backend.get_counters()["max_reach"])], dtype=torch.float64,
-                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(reach, op=dist.ReduceOp.MAX)
+        c = self.backend.get_counters()
+        reach = torch.tensor([float(c.get("max_reach_seen", c["max_reach"]))], dtype=torch.float64,     # the running maximum, not the last step's
+                             device="cuda" if (dist.is_initialized() and dist.get_backend() == "nccl") else "cpu")
+        if dist.is_initialized() and self.world > 1:
+            dist.all_reduce(reach, op=dist.ReduceOp.MAX)
         have = self.backend.halo_rows
         if int(reach[0]) >= have:
             self.backend.set_halo_rows(have + 1)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = K.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.picles_abi_version() == 1
+    assert lib.picles_abi_version() == 2
 
 
 def test_struct_layouts_match_header_sizes():
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(K.PiclesPhys) == 11 * 8 + 6 * 4 + 8
     assert C.sizeof(K.PiclesOde) == 4 * 8 + 2 * 4 + 8 + 4 * 8
     assert C.sizeof(K.PiclesModel) == 8 + 5 * 8
-    assert C.sizeof(K.PiclesCounters) == 8 * 8 + 8
+    assert C.sizeof(K.PiclesCounters) == 8 * 8 + 8 + 8
 
 
 def test_no_cpu_fallback():

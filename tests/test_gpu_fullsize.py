@@ -126,10 +126,11 @@ def _anchor_lne(case, k):
 
 
 # ------------------------------------------------------------------------------------------------ cfg 2
-@pytest.mark.parametrize("U,V,periodic", [(10.0, 10.0, False), (-10.0, 10.0, True), (5.0, 5.0, False), (0.0, -10.0, True)])
-def test_cfg2_T04_256x256_x36_movie(U, V, periodic):
+@pytest.mark.parametrize("U,V,periodic,steps_A", [(10.0, 10.0, False, 12), (-10.0, 10.0, True, 12), (5.0, 5.0, False, 36),
+                                                  (0.0, -10.0, True, 12)])
+def test_cfg2_T04_256x256_x36_movie(U, V, periodic, steps_A):
     n = 256 // SCALE
-    _parity(lambda: configs.T04_2D_reg_test(n=n, L=4000.0 * (n - 1), U10=U, V10=V, periodic=periodic), 36, 36, 2e-2)
+    _parity(lambda: configs.T04_2D_reg_test(n=n, L=4000.0 * (n - 1), U10=U, V10=V, periodic=periodic), 36, steps_A, 2e-2)
 
 
 @pytest.mark.parametrize("U,V,anchor", [(-10.0, 10.0, "cfg2_T04_m10_10"), (5.0, 5.0, "cfg2_T04_5_5"), (10.0, 3.0, "cfg2_T04_10_3")])

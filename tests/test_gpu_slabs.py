@@ -22,7 +22,7 @@ def _free_port():
 
 def _cfg(name):
     from picles_amd import configs
-    return {"periodic": lambda: configs.bench06_box(n=64, dx=1500.0),
+    return {"periodic": lambda: configs.bench06_box(n=64, dx=1500.0, winds=configs.smooth_winds(10.0, 8.0, 64 * 1500.0, 64 * 1500.0)),
             "nonperiodic_generic": lambda: configs.T04_2D_reg_test(U10=10.0, V10=3.0, periodic=False, n=45, L=176e3),
             "calm": lambda: configs.growing_decaying_winds(n=48),
             "periodic_model_ring": lambda: configs.T04_2D_reg_test(U10=-10.0, V10=10.0, periodic=True, n=45, L=176e3),
@@ -176,7 +176,7 @@ def _ring_worker(rank, port, outdir):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     cfg = _cfg("periodic")
-    model = SlabModel(cfg.model, 0, 1, device=0, halo_rows=2, ring_of_one=True)
+    model = SlabModel(cfg.model, 0, 1, device=0, halo_rows=2, ring_of_one=True, native_ring=False)   # the torch.distributed-driven loop
     assert model.ex is not None and model.ex.staged is False and model.use_streams
     model.seed()
     for _ in range(7):
@@ -189,8 +189,9 @@ def _ring_worker(rank, port, outdir):
 def test_ring_of_one_runs_the_multi_gpu_host_loop_over_rccl(tmp_path):
     """the whole N > 1 step loop of parallel.SlabModel — fused edge / interior launches on two streams, RCCL isend /
     irecv of the halo blocks in place every step, stream hand-overs — on a one-rank RCCL group whose ring closes on
-    itself.  (The whole-grid context wraps in y by itself and does not read its ghost rows, so the result must equal
-    the plain single-context run bitwise.)"""
+    itself.  The context runs in slab mode (picles_set_slab_mode): its periodic y wrap goes through the ghost rows, so
+    the pull CONSUMES the rows RCCL delivered in place, ordered behind the edge kernel — and the result must still equal
+    the plain single-context run bitwise."""
     from picles_amd.parallel import SlabModel
     mp.spawn(_ring_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     S = np.load(tmp_path / "state.npy")

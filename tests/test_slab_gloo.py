@@ -52,8 +52,14 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
     model = SlabModel(cfg.model, rank, world, halo_rows=halo, backend_factory=fac, auto_halo_every=auto, fallback_group=fb)
     assert model.ex.staged is False            # the CPU rehearsal exchanges in place too: P2P straight on the halo blocks
     if name == "fallback":
-        model.ex._fail_next_inplace = True      # the in-place exchange fails during the warm-up (on every rank alike:
-                                                # a rank that failed alone would leave its neighbours waiting) ...
+        # the in-place exchange fails during the warm-up (on every rank alike: a rank that failed alone would leave its
+        # neighbours waiting) ... — fault injection lives here, in the test, not in the product
+        real_start = model.ex.start
+
+        def failing_start():
+            model.ex.start = real_start
+            raise RuntimeError("injected failure of the in-place halo exchange")
+        model.ex.start = failing_start
     model.seed()
     if name == "fallback":
         assert model.ex.staged is True          # ... and every rank has switched to staging, collectively
