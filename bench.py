@@ -17,6 +17,8 @@ import sys
 import time
 from pathlib import Path
 
+import numpy as np
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -90,7 +92,7 @@ def measured_traffic(args, world):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled: profiles/*_pmc_summary.md) — only when
     the profile was taken on this exact workload; PMC counters cannot be read live in a timed run."""
-    f = ROOT / "profiles" / "r1_pmc_traffic.json"
+    f = next((q for q in (ROOT / "profiles" / "r2_pmc_traffic.json", ROOT / "profiles" / "r1_pmc_traffic.json") if q.exists()), None)
     try:
         d = json.loads(f.read_text())
         if (world == 1 and d["config"]["n"] == args.n and tuple(d["config"]["winds"]) == tuple(args.winds)
@@ -113,6 +115,7 @@ def main():
                     help="halo rows = scatter reach the slabs cover (the box reaches 2 cells after ~45 steps; ignored for one GPU)")
     ap.add_argument("--atomic", action="store_true", help="LDS-tiled atomic push scatter instead of the pull")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (generic wind direction, default solver)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--deadband", type=float, default=0.0,
@@ -122,6 +125,8 @@ def main():
     ap.add_argument("--ring-of-one", action="store_true",
                     help="rehearsal on ONE GPU of the N > 1 host loop over the real transport: a one-rank RCCL group, edge / "
                          "interior launches on two streams, the halo blocks sent to ourselves every step")
+    ap.add_argument("--python-loop", action="store_true",
+                    help="drive the slab exchange from Python (torch.distributed P2P per step) instead of the native ring")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")
     args = ap.parse_args()
@@ -157,7 +162,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    if world == 1 and args.ring_of_one:
+    if world == 1 and args.ring_of_one and args.python_loop:
         import socket
         import torch.distributed as dist
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
@@ -167,34 +172,38 @@ def main():
     from picles_amd import configs, _capi as K
     from picles_amd.parallel import SlabModel
 
-    cfg = configs.box4096(n=args.n, U10=args.winds[0], V10=args.winds[1])
-    cfg.model["ODEsys"].dir_deadband = args.deadband
-    cfg.model["ODEsets"].solver = args.solver
-    model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo,
-                      fallback_group=fallback if world > 1 else None, ring_of_one=args.ring_of_one)
-    model.seed()
+    use_dist = world > 1
     flags = K.STEP_ZERO_FIRST | (K.STEP_ATOMIC if args.atomic else 0)
     W, Ksteps = args.warmup, args.steps
-    for _ in range(W):
-        model.time_step(cfg.Δt, flags)
-    model.sync()
-    model.backend.reset_counters()
-    model.backend.enable_timing(True)
 
-    use_dist = world > 1 or args.ring_of_one      # the ring of one exercises the same collectives on its one-rank group
-
-    def barrier():
+    def barrier(model):
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         model.sync()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(Ksteps):
-        model.time_step(cfg.Δt, flags)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def measure(winds, solver, deadband, K_, W_):
+        """seed, W_ warm-up steps, then EXACTLY K_ timed steps between barriers.  The timed region is ONE call into the
+        library (picles_run_steps on one GPU, picles_slab_run_steps on a slab ring): no interpreter between the steps."""
+        cfg = configs.box4096(n=args.n, U10=winds[0], V10=winds[1])
+        cfg.model["ODEsys"].dir_deadband = deadband
+        cfg.model["ODEsets"].solver = solver
+        model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo,
+                          ring_of_one=args.ring_of_one,
+                          native_ring=None if (args.backend == "nccl" and not args.python_loop) else False)
+        model.seed()
+        model.run_steps(cfg.Δt, W_, flags)
+        model.sync()
+        model.backend.reset_counters()
+        model.backend.enable_timing(True)
+        barrier(model)
+        t0 = time.perf_counter()
+        model.run_steps(cfg.Δt, K_, flags)
+        model.host_enqueue_s = time.perf_counter() - t0      # host side of the step loop (the launches are asynchronous)
+        barrier(model)
+        return model, time.perf_counter() - t0
+
+    model, elapsed = measure(args.winds, args.solver, args.deadband, Ksteps, W)
 
     cnt = model.backend.get_counters()
     tim = model.backend.get_timing()
@@ -212,6 +221,20 @@ def main():
     overflow = float(vals[3])
     if overflow > 0:
         raise SystemExit(f"halo overflow ({overflow} particles travelled beyond --halo {args.halo}): result invalid")
+    # result check outside the timed region: the BASELINE box is homogeneous and periodic, so after any number of steps the
+    # energy plane must be one value on every node of every slab (a lost or doubled halo row, a wrong neighbour across a slab
+    # seam or a stale ghost row breaks it at the seams)
+    state_check = None
+    if args.winds[0] == args.winds[1] or world > 1:
+        e = model.get_state()[..., 0]
+        ext = torch.tensor([float(e.min()), -float(e.max())], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        if use_dist:
+            dist.all_reduce(ext, op=dist.ReduceOp.MIN)
+        emin, emax = float(ext[0]), -float(ext[1])
+        state_check = {"e_min": emin, "e_max": emax, "rel_spread": (emax - emin) / emax}
+        if not (emin > 0 and state_check["rel_spread"] < 1e-6):
+            raise SystemExit(f"State check failed: the homogeneous periodic box is not uniform across the {world} slab(s): {state_check}")
+        del e
 
     if rank == 0:
         value = n_total * Ksteps / elapsed
@@ -272,6 +295,37 @@ def main():
             "kernel_ms_per_step": {"step_or_advance": tim["advance_ms"] / Ksteps, "scatter_remesh": tim["scatter_ms"] / Ksteps,
                                    "remesh": tim["remesh_ms"] / Ksteps},
         }
+        samples = np.sort(model.backend.get_timing_samples(0))
+        if samples.size:
+            out["roofline"]["min_launch_ms"] = float(samples[0])
+            out["roofline"]["median_launch_ms"] = float(np.median(samples))
+            out["roofline"]["launches"] = int(samples.size)
+        out["state_check"] = state_check
+        out["config"]["host_enqueue_us_per_step"] = 1e6 * model.host_enqueue_s / Ksteps
+        out["config"]["step_loop"] = ("native: picles_slab_run_steps (RCCL send/recv issued from C)" if model.native else
+                                      ("native: picles_run_steps" if world == 1 else "python: torch.distributed P2P per step"))
+        if world == 1 and not args.no_secondary and not args.atomic and not args.ring_of_one:
+            # the honest spread: the BASELINE winds (10,10) are the best case of the explicit pair; a generic
+            # wind direction and the reference's DEFAULT solver, same box, same process
+            del model
+            sec = []
+            K2 = max(3, min(Ksteps, 10))
+            for winds, solver in (((10.0, 3.0), "DP5"), ((10.0, 3.0), "AutoTsit5"), ((10.0, 10.0), "AutoTsit5")):
+                if tuple(winds) == tuple(args.winds) and solver == args.solver:
+                    continue
+                m2, el2 = measure(winds, solver, 0.0, K2, 2)
+                c2 = m2.backend.get_counters()
+                sm = np.sort(m2.backend.get_timing_samples(0))
+                rate = m2.n_stepped * K2 / el2
+                rps = c2["rhs_evals"] / max(m2.n_stepped * K2, 1)
+                tf = c2["rhs_evals"] * FLOP_PER_RHS / el2 / 1e12
+                sec.append({"winds": list(winds), "solver": solver, "steps": K2, "ms_per_step": 1e3 * el2 / K2, "value": rate,
+                            "rhs_evals_per_particle_step": rps, "fp64_frac": tf / FP64_PEAK_TFLOPS,
+                            "hbm_frac": B_ALG * rate / 1e9 / HBM_PEAK_GBPS,
+                            "kernel_ms_min_median": [float(sm[0]), float(np.median(sm))] if sm.size else None,
+                            "halo_overflow": int(c2["halo_overflow"])})
+                del m2
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, W, Ksteps)

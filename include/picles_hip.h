@@ -197,6 +197,9 @@ int32_t picles_get_counters(picles_ctx *ctx, picles_counters *c);   /* syncs */
 int32_t picles_reset_counters(picles_ctx *ctx);
 int32_t picles_enable_timing(picles_ctx *ctx, int32_t on);
 int32_t picles_get_timing(picles_ctx *ctx, picles_timing *t);       /* syncs */
+/* per-launch device durations [ms] since picles_enable_timing(1): kind 0 = step / advance launches, 1 = scatter, 2 = remesh.
+ * Copies up to cap values; returns the number of samples held (>= 0) or an error (< 0). */
+int32_t picles_get_timing_samples(picles_ctx *ctx, int32_t kind, double *out_ms, int32_t cap);
 int32_t picles_sync(picles_ctx *ctx);
 
 /* ---- split phases for the slab-partitioned (multi-GPU) step -------------------

@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -642,6 +643,18 @@ __device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i,
     else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
 }
 
+/* reach the pull of local row jl must cover.  A whole-grid context follows the reach its own advance measured.  A slab
+ * covers halo_rows for the rows that can receive from a neighbour's particles (the edge rows: the neighbour's reach is not
+ * known here), and for its interior rows — fed by own particles only — again the measured reach, which is what keeps the
+ * common case at 9 candidates per node instead of (2 halo_rows + 1)².  Any reach >= the true one gives the same bits. */
+__device__ __forceinline__ int pull_reach(const GridP &G, const Arrays &A, int jl)
+{
+    if (G.Rp > 0 && (jl < G.R || jl >= G.ny_loc - G.R)) return G.Rp;
+    int m = *A.max_reach;
+    if (m < 1) m = 1;
+    return (G.Rp > 0 && m > G.Rp) ? G.Rp : m;
+}
+
 template <bool REMESH>
 __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, int accum, int movie,
                                                    double clock, double DT)
@@ -653,9 +666,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if (accum) { s0 = A.state[t]; s1 = A.state[t + A.n]; s2 = A.state[t + 2 * A.n]; }
-        int R = G.Rp;
-        if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
-        pull_any(G, A, i, jl, R, s0, s1, s2);
+        pull_any(G, A, i, jl, pull_reach(G, A, jl), s0, s1, s2);
         if (movie) {
             A.movie[t] = s0; A.movie[t + A.n] = s1; A.movie[t + 2 * A.n] = s2;
             A.state[t] = 0.0; A.state[t + A.n] = 0.0; A.state[t + 2 * A.n] = 0.0;
@@ -699,9 +710,7 @@ __global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, 
     if (active) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        int R = G.Rp;
-        if (R == 0) { R = *A.max_reach; if (R < 1) R = 1; }
-        pull_any(G, A, i, jl, R, s0, s1, s2);
+        pull_any(G, A, i, jl, pull_reach(G, A, jl), s0, s1, s2);
         A.state[t] = s0; A.state[t + A.n] = s1; A.state[t + 2 * A.n] = s2;
         unsigned char pf = A.pflags[t];
         if (pf & PF_STEPPED) {
@@ -958,6 +967,7 @@ struct picles_ctx {
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> ev_used, ev_free;
     picles_timing tim{};
+    std::vector<float> tim_samples[3];   /* per-launch durations by kind (advance / scatter / remesh) */
     std::string err;
     /* snapshot ring (run! stores) */
     int store_slots = 0, store_head = 0, store_count = 0;
@@ -1015,6 +1025,7 @@ static void timing_collect(picles_ctx *c)
         hipEventSynchronize(e.b);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e.a, e.b);
+        if (e.kind >= 0 && e.kind < 3 && c->tim_samples[e.kind].size() < (1u << 20)) c->tim_samples[e.kind].push_back(ms);
         switch (e.kind) {
         case 0: c->tim.advance_ms += ms; c->tim.advance_launches++; break;
         case 1: c->tim.scatter_ms += ms; c->tim.scatter_launches++; break;
@@ -1841,7 +1852,7 @@ PX_EXPORT int32_t picles_enable_timing(picles_ctx *c, int32_t on)
     { int rc = flush(c); if (rc) return rc; }
     timing_collect(c);
     c->timing = on != 0;
-    if (on) memset(&c->tim, 0, sizeof(c->tim));
+    if (on) { memset(&c->tim, 0, sizeof(c->tim)); for (auto &v : c->tim_samples) v.clear(); }
     return 0;
 }
 
@@ -1853,6 +1864,18 @@ PX_EXPORT int32_t picles_get_timing(picles_ctx *c, picles_timing *t)
     timing_collect(c);
     *t = c->tim;
     return 0;
+}
+
+PX_EXPORT int32_t picles_get_timing_samples(picles_ctx *c, int32_t kind, double *out_ms, int32_t cap)
+{
+    if (!c || kind < 0 || kind > 2 || cap < 0 || (cap > 0 && !out_ms)) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc = flush(c); if (rc) return rc; }
+    timing_collect(c);
+    const std::vector<float> &v = c->tim_samples[kind];
+    int n = (int)std::min<size_t>(v.size(), (size_t)cap);
+    for (int k = 0; k < n; k++) out_ms[k] = v[k];
+    return (int32_t)v.size();
 }
 
 /* ---- snapshot ring ---- */
@@ -2103,8 +2126,12 @@ PX_EXPORT int32_t picles_slab_comm_init(picles_ctx *c, const void *id128, int32_
         picles_slab_comm_destroy(c);
         return -11;
     }
-    HIPCHK(c, hipStreamCreateWithFlags(&R->sE, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&R->sM, hipStreamNonBlocking));
+    /* the edge stream carries the latency-critical chain (edge rows -> exchange -> the neighbour's next step): highest
+     * priority, so its few workgroups and the RCCL kernels are not queued behind the interior launch */
+    int pr_lo = 0, pr_hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&R->sE, hipStreamNonBlocking, pr_hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&R->sM, hipStreamNonBlocking, pr_lo));
     HIPCHK(c, hipEventCreateWithFlags(&R->evE, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&R->evM, hipEventDisableTiming));
     return 0;

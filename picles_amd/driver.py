@@ -6,7 +6,9 @@ raises — there is no CPU path in the product.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -24,6 +26,20 @@ def _col(a, n):
     if a.size != n:
         raise ValueError(f"expected {n} values, got {a.size}")
     return a
+
+
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    """contexts still alive at interpreter exit are destroyed HERE, while the HIP runtime and RCCL are intact —
+    not from __del__ during module teardown, after other libraries' exit handlers may have run"""
+    for m in list(_live):
+        try:
+            m.close()
+        except Exception:
+            pass
 
 
 class HipModel:
@@ -47,6 +63,8 @@ class HipModel:
             msg = self.lib.picles_last_error(None)
             raise K.PiclesError(f"picles_create failed (rc={rc}): {msg.decode() if msg else '?'}")
         self.h = h
+        self.gen = 0          # bumped by every call that can change the device State (LazyState validates its mirror against it)
+        _live.add(self)
 
     # ---- lifetime ----
     def close(self):
@@ -89,25 +107,31 @@ class HipModel:
         return [a.reshape((self.Nx, self.ny_loc), order="F") for a in out]
 
     def seed(self, t0=0.0):
+        self.gen += 1
         self._ck(self.lib.picles_seed(self.h, t0), "picles_seed")
 
     # ---- stepping ----
     def time_step(self, dt, flags=0):
+        self.gen += 1
         self._ck(self.lib.picles_time_step(self.h, dt, flags), "picles_time_step")
 
     def run_steps(self, dt, n):
+        self.gen += 1
         self._ck(self.lib.picles_run_steps(self.h, dt, n), "picles_run_steps")
 
     def advance(self, dt, flags=0):
+        self.gen += 1
         self._ck(self.lib.picles_advance(self.h, dt, flags), "picles_advance")
 
     def remesh(self, dt):
+        self.gen += 1
         self._ck(self.lib.picles_remesh(self.h, dt), "picles_remesh")
 
     def tick(self, dt):
         self._ck(self.lib.picles_tick(self.h, dt), "picles_tick")
 
     def zero_state(self):
+        self.gen += 1
         self._ck(self.lib.picles_zero_state(self.h), "picles_zero_state")
 
     def sync(self):
@@ -119,12 +143,15 @@ class HipModel:
 
     # ---- split phases (slab-partitioned step) ----
     def begin_step(self, dt, flags=0):
+        self.gen += 1
         self._ck(self.lib.picles_begin_step(self.h, dt, flags), "picles_begin_step")
 
     def advance_rows(self, which, stream=None):
+        self.gen += 1
         self._ck(self.lib.picles_advance_rows(self.h, which, stream), "picles_advance_rows")
 
     def scatter_remesh(self, stream=None):
+        self.gen += 1
         self._ck(self.lib.picles_scatter_remesh(self.h, stream), "picles_scatter_remesh")
 
     def begin_fused_step(self, dt) -> bool:
@@ -135,9 +162,11 @@ class HipModel:
         return rc == 0
 
     def step_rows(self, which, stream=None):
+        self.gen += 1
         self._ck(self.lib.picles_step_rows(self.h, which, stream), "picles_step_rows")
 
     def end_fused_step(self):
+        self.gen += 1
         self._ck(self.lib.picles_end_fused_step(self.h), "picles_end_fused_step")
 
     def halo_send(self, side):
@@ -155,6 +184,7 @@ class HipModel:
         return self.lib.picles_halo_rows(self.h)
 
     def set_halo_rows(self, r):
+        self.gen += 1
         self._ck(self.lib.picles_set_halo_rows(self.h, r), "picles_set_halo_rows")
 
     def set_slab_mode(self, on=True):
@@ -176,6 +206,7 @@ class HipModel:
         self._ck(self.lib.picles_slab_comm_init(self.h, buf, rank, world), "picles_slab_comm_init")
 
     def slab_run_steps(self, dt, n, flags=K.STEP_ZERO_FIRST):
+        self.gen += 1
         self._ck(self.lib.picles_slab_run_steps(self.h, dt, n, flags), "picles_slab_run_steps")
 
     def slab_exchange(self):
@@ -196,6 +227,7 @@ class HipModel:
         return s.reshape((self.Nx, self.ny_loc, 3), order="F")
 
     def set_state(self, s):
+        self.gen += 1
         s = _col(s, 3 * self.N)
         self._ck(self.lib.picles_set_state(self.h, K.dptr(s)), "picles_set_state")
 
@@ -234,6 +266,7 @@ class HipModel:
                 bnd.reshape(sh, order="F"), st.reshape(sh, order="F"))
 
     def set_particles(self, z, on):
+        self.gen += 1
         z = _col(z, 5 * self.N)
         on = np.ascontiguousarray(np.asarray(on, dtype=np.uint8).reshape(-1, order="F"))
         self._ck(self.lib.picles_set_particles(self.h, K.dptr(z), on.ctypes.data_as(K.c_uint8_p)),
@@ -241,6 +274,7 @@ class HipModel:
 
     def scatter_particles(self, ij, xy, charge):
         """generic push_to_grid! of a particle list (ij: (n,2) int, xy: (n,2), charge: (n,3))"""
+        self.gen += 1
         ij = np.ascontiguousarray(np.asarray(ij, dtype=np.int32).T)
         xy = np.ascontiguousarray(np.asarray(xy, dtype=np.float64).T)
         ch = np.ascontiguousarray(np.asarray(charge, dtype=np.float64).T)
@@ -258,6 +292,15 @@ class HipModel:
 
     def enable_timing(self, on=True):
         self._ck(self.lib.picles_enable_timing(self.h, int(on)), "picles_enable_timing")
+
+    def get_timing_samples(self, kind=0):
+        """per-launch device durations [ms] of the step/advance (0), scatter (1) or remesh (2) kernels"""
+        n = self.lib.picles_get_timing_samples(self.h, kind, None, 0)
+        if n < 0:
+            self._ck(n, "picles_get_timing_samples")
+        out = np.empty(max(n, 1))
+        n = self.lib.picles_get_timing_samples(self.h, kind, K.dptr(out), n)
+        return out[:max(n, 0)]
 
     def get_timing(self):
         t = K.PiclesTiming()

@@ -30,6 +30,112 @@ class Clock:
         return f"Clock(time={self.time}, iteration={self.iteration})"
 
 
+class LazyState:
+    """`model.State` as the rest of PiCLES sees it (a [Nx, Ny, 3] array: run.jl:75-79,94-112 zero it, store it, plot it)
+    while the field itself lives in HBM.  The host mirror is pulled only when somebody READS it, and the two writes
+    run! performs are recorded instead of executed:
+
+      State .= 0 (fill / `S[...] = 0`)  ->  `zeroed`: the next time_step! passes PICLES_STEP_ZERO_FIRST (the zero-fill is
+                                            fused into the scatter's store; nothing crosses PCIe, the steps stay fused)
+      any other write                    ->  `dirty`: the host copy is uploaded before the next step
+
+    The Julia shim (picles_amd/julia/PiCLESHip.jl, `LazyState <: AbstractArray{Float64,3}`) carries exactly this logic;
+    this class is its executed twin (tests/test_gpu_lazy_state.py)."""
+
+    def __init__(self, backend, shape):
+        self._b, self.shape, self.dtype, self.ndim = backend, tuple(shape), np.dtype(np.float64), 3
+        self._host = None
+        self._gen = getattr(backend, "gen", None)
+        self.host_valid = False     # the host mirror equals the device field
+        self.dirty = False          # the host mirror was written: upload before the next step
+        self.zeroed = False         # the last write was State .= 0
+        self.pulls = 0              # device -> host copies so far (what the tests count)
+        self.uploads = 0
+
+    # ---- reads ----
+    def _valid(self):
+        # the mirror is current only while nothing has touched the device field behind our back (HipModel.gen counts the
+        # calls that can; a backend without the counter is re-read every time)
+        return self.host_valid and self._host is not None and getattr(self._b, "gen", None) == self._gen
+
+    def _pull(self):
+        if self.zeroed and not self.dirty and getattr(self._b, "gen", None) == self._gen:
+            if not self._valid():
+                self._host = np.zeros(self.shape)
+                self.host_valid = True
+            return self._host
+        if not (self._valid() or self.dirty):
+            self._host = self._b.get_state()
+            self._gen = getattr(self._b, "gen", None)
+            self.host_valid, self.zeroed = True, False
+            self.pulls += 1
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._pull()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, k):
+        return self._pull()[k]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getattr__(self, name):        # copy(), max(), sum(), reshape(), ... : whatever an ndarray offers, on the pulled mirror
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._pull(), name)
+
+    def __repr__(self):
+        return f"LazyState(shape={self.shape}, host_valid={self.host_valid}, dirty={self.dirty}, zeroed={self.zeroed})"
+
+    # ---- writes ----
+    def fill(self, value):
+        if value == 0:
+            self.zeroed, self.dirty, self.host_valid = True, False, False
+            self._host = None
+            self._gen = getattr(self._b, "gen", None)
+        else:
+            self._pull().fill(value)
+            self.dirty, self.zeroed = True, False
+
+    def __setitem__(self, k, value):
+        whole = k is Ellipsis or (isinstance(k, slice) and k == slice(None)) or \
+            (isinstance(k, tuple) and all(x is Ellipsis or (isinstance(x, slice) and x == slice(None)) for x in k))
+        if whole and np.isscalar(value):
+            return self.fill(value)
+        self._pull()[k] = value
+        self.dirty, self.zeroed = True, False
+
+    # ---- the stepper's side ----
+    def before_step(self):
+        """called by time_step!: returns True if the step starts from a zeroed State (ZERO_FIRST); uploads a written mirror"""
+        if self.dirty:
+            self._b.set_state(self._host)
+            self.uploads += 1
+            self.dirty = False
+            return False
+        return self.zeroed and getattr(self._b, "gen", None) == self._gen
+
+    def after_step(self):
+        self.host_valid, self.zeroed, self.dirty = False, False, False
+        self._host = None
+        self._gen = getattr(self._b, "gen", None)
+
+
+def _forward(op):
+    def f(self, *args):
+        return getattr(self._pull(), op)(*args)
+    f.__name__ = op
+    return f
+
+
+for _op in ("__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__add__", "__radd__", "__sub__", "__rsub__", "__mul__",
+            "__rmul__", "__truediv__", "__rtruediv__", "__pow__", "__neg__", "__abs__", "__iter__"):
+    setattr(LazyState, _op, _forward(_op))
+LazyState.__hash__ = None
+
+
 def build_structs(grid: TwoDCartesianGridMesh, ODEsys: ParticleSystem2D, ODEsets: ODESettings,
                   ODEdefaults, minimal_state, periodic_boundary: bool, j_begin=0, j_end=None):
     """WaveGrowth2D keyword arguments -> the four C structs of include/picles_hip.h"""
@@ -147,6 +253,7 @@ class WaveGrowth2D:
         if hasattr(grid, "metric"):     # spherical mesh: per-node projection + great-circle term
             self.backend.set_metric(*grid.metric())
         self._wind_window = None
+        self._state = LazyState(self.backend, (g.Nx, g.Ny, 3))
 
     # ---- winds ----
     def _is_static(self, dt):
@@ -185,11 +292,23 @@ class WaveGrowth2D:
     # ---- State lives on the device ----
     @property
     def State(self):
-        return self.backend.get_state()
+        """the lazy host view of the device field (LazyState): reading pulls once, `State.fill(0)` / `State[...] = 0`
+        is fused into the next step"""
+        return self._state
 
     @State.setter
     def State(self, value):
-        self.backend.set_state(value)
+        self._state[...] = value if np.isscalar(value) else np.asarray(value, dtype=np.float64)
+
+    def check_counters(self):
+        """raise if particles were dropped without being scattered: beyond the reach cap (a deliberate limit of this
+        implementation) or with a non-finite position (the reference would throw there)"""
+        c = self.backend.get_counters()
+        if c.get("halo_overflow", 0) or c.get("dropped_nonfinite", 0):
+            raise K.PiclesError(f"{c['halo_overflow']} particles travelled beyond the scatter reach this context covers and "
+                                f"{c.get('dropped_nonfinite', 0)} had a non-finite position: they were NOT scattered "
+                                "(State is incomplete)")
+        return c
 
     @property
     def ParticleCollection(self):

@@ -119,8 +119,8 @@ def run(sim: Simulation, store=False, pickup=False, cash_store=False, debug=Fals
             m.clock.iteration += n
         sim.running = False
     while sim.running:
-        # State .= 0 is fused into the scatter kernel (zero_first)
-        time_step(sim.model, sim.Δt, debug=debug, zero_first=True)
+        sim.model.State.fill(0.0)          # State .= 0 (run.jl:75-79): recorded by the lazy view, fused into the scatter's store
+        time_step(sim.model, sim.Δt, debug=debug)
         if store:
             if ring:   # asynchronous: D2H of step k overlaps the kernels of steps k+1, k+2
                 b = sim.model.backend
@@ -140,4 +140,6 @@ def run(sim: Simulation, store=False, pickup=False, cash_store=False, debug=Fals
                 sim.store.write(b.store_pop()[0])
         sim.store.close()
     sim.model.backend.sync() if hasattr(sim.model.backend, "sync") else None
+    if hasattr(sim.model, "check_counters"):
+        sim.model.check_counters()         # particles beyond the reach cap / with non-finite positions were not scattered: say so
     sim.run_wall_time += 1e-9 * (time.perf_counter_ns() - t0)

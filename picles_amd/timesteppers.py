@@ -11,15 +11,28 @@ def time_step(model, Δt: float, callbacks=None, debug=False, zero_first=False):
     """advance all ocean_points particles, scatter, remesh, tick (TimeSteppers.jl:109-166).
     `zero_first` fuses run!'s `State .= 0` (run.jl:75-79) into the scatter."""
     model.upload_winds(model.clock.time, Δt)
+    st = getattr(model, "_state", None)
+    if st is not None:
+        zero_first = st.before_step() or zero_first      # a recorded `State .= 0` rides on the scatter's store
     model.backend.time_step(Δt, K.STEP_ZERO_FIRST if zero_first else 0)
+    if st is not None:
+        st.after_step()
     model.clock.time += Δt
     model.clock.iteration += 1
+    if debug:
+        model.check_counters()
 
 
 def time_step_advance(model, Δt: float, FailedCollection=None):
     """TimeSteppers.jl:168-180"""
     model.upload_winds(model.clock.time, Δt)
+    st = getattr(model, "_state", None)
+    zero_first = st.before_step() if st is not None else False
+    if zero_first:
+        model.backend.zero_state()
     model.backend.advance(Δt, 0)
+    if st is not None:
+        st.after_step()
 
 
 def time_step_remesh(model, Δt: float):
@@ -32,7 +45,13 @@ def movie_time_step(model, Δt: float, callbacks=None, debug=False):
     """TimeSteppers.jl:212-247: State is snapshotted into MovieState between advance and remesh
     and zeroed after the remesh."""
     model.upload_winds(model.clock.time, Δt)
+    st = getattr(model, "_state", None)
+    if st is not None:
+        if st.before_step():
+            model.backend.zero_state()
     model.backend.time_step(Δt, K.STEP_MOVIE)
+    if st is not None:
+        st.after_step()
     model.MovieState = model.backend.get_movie_state()
     model.clock.time += Δt
     model.clock.iteration += 1

@@ -103,7 +103,6 @@ def test_native_ring_full_width_rows_4096():
     """row length of the BASELINE box (4096 nodes, the 197 KB halo block of DESIGN §6) at 1/16 of its height"""
     n = 4096
     cfg = configs.bench06_box(n=n, winds=configs.smooth_winds(10.0, 10.0, 2000.0 * n, 2000.0 * n, direction=False))
-    import dataclasses
     # a 4096 x 256 periodic mesh
     from picles_amd.grids import TwoDCartesianGridMesh
     ny = 256
