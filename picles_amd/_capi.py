@@ -160,17 +160,34 @@ class PiclesError(RuntimeError):
     pass
 
 
+def _settle_rocm_runtime():
+    """PyTorch's ROCm wheels bundle their own user-space runtime (libamdhip64, librccl, libhsa-runtime64, ...) and the
+    dynamic linker keeps whichever copy of a SONAME is loaded FIRST.  A process that dlopens libpicles_hip.so (system
+    runtime) and imports torch afterwards ends up with a mix of system and bundled libraries — it computes correctly and
+    then aborts at exit (glibc "double free or corruption", seen on the MI355X boxes in round 2).  The multi-GPU driver and
+    the tests do import torch, so: if torch is installed it is imported before the library is opened.  A host that never
+    touches torch can opt out with PICLES_NO_TORCH_PRELOAD=1."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("PICLES_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load(path: os.PathLike | None = None) -> C.CDLL:
     """dlopen libpicles_hip.so and type every exported symbol.  Raises if it is missing:
     the product has no CPU path."""
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("PICLES_HIP_LIB", LIB_PATH))     # same override as the Julia shim
     if not p.exists():
         raise PiclesError(
             f"{p} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C picles_amd/csrc)")
+    _settle_rocm_runtime()
     lib = C.CDLL(str(p))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

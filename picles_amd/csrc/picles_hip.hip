@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -698,8 +699,11 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
  * ---------------------------------------------------------------------------------------- */
 /* STATIC = false: winds linear in time over the step window (u0,v0 -> u1,v1); the remesh of the previous step
  * needs the wind at ITS start-of-step clock = level 0 of the previous window, kept in (uP, vP) */
+/* Occupancy: the explicit pairs fit 168 VGPRs = three waves per SIMD; the auto-switching flavour (Rosenbrock23 peaks at
+ * ~220 live registers) is built for two waves with no scratch — measured equal to the spilling three-wave build, and a
+ * two-phase split was measured slower (profiles/r2_two_phase_auto_experiment.md). */
 template <bool FAST, bool TSIT, bool DB, bool STATIC, bool METRIC, bool AUTO>
-__global__ void __launch_bounds__(256, FAST ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
+__global__ void __launch_bounds__(256, (FAST && !AUTO) ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
     dp_device_init(TSIT ? 1 : 0);
@@ -783,6 +787,32 @@ __device__ __forceinline__ void global_add3(const GridP &G, const Arrays &A, int
     unsafeAtomicAdd(&A.state[t + 2 * A.n], a2);
 }
 
+/* Wave-level pre-reduction of same-destination contributions (the "wavefront-reduced atomics" of the scatter design).
+ * Every lane offers one contribution (value triple q, destination key; key < 0: nothing).  Lanes that are neighbours in
+ * the wave and target the same node form a run; the run is summed with a segmented shuffle scan and its first lane
+ * alone issues the LDS / global atomic.  With one particle per cell and lanes laid along x this turns the upper-x corner
+ * of lane k and the lower-x corner of lane k+1 into ONE atomic (after rotating the upper corners by one lane); with a
+ * cell-sorted particle list it also folds all particles of one cell.  Runs are short (2 in the identity layout), so the
+ * scan stops as soon as no lane has a partner left: usually after one step. */
+__device__ __forceinline__ bool wave_fold_runs(int key, double &q0, double &q1, double &q2)
+{
+    const int lane = threadIdx.x & 63;
+    const int kl = __shfl_up(key, 1, 64);
+    const bool head = (lane == 0) || (kl != key) || (key < 0);
+    if (__ballot(!head) == 0) return key >= 0;             /* no two neighbouring lanes share a node */
+    /* run id = number of run heads at or below this lane; two lanes belong to the same run iff the ids agree */
+    const unsigned long long hb = __ballot(head);
+    const int rid = __popcll(hb & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull)));
+    for (int o = 1; o < 64; o <<= 1) {
+        const double a0 = __shfl_down(q0, o, 64), a1 = __shfl_down(q1, o, 64), a2 = __shfl_down(q2, o, 64);
+        const int r2 = __shfl_down(rid, o, 64);
+        const bool take = (lane + o < 64) && (r2 == rid);
+        if (take) { q0 += a0; q1 += a1; q2 += a2; }
+        if (__ballot(take) == 0) break;                      /* every run is folded */
+    }
+    return head && key >= 0;
+}
+
 template <bool IDENTITY>
 __global__ void __launch_bounds__(256) k_push_tiles(GridP G, Arrays A, int ntx,
                                                       const int *seg_start, const int *perm,
@@ -797,43 +827,82 @@ __global__ void __launch_bounds__(256) k_push_tiles(GridP G, Arrays A, int ntx,
     int count, base = 0;
     if (IDENTITY) count = PT_TX * PT_TY;
     else { base = seg_start[blockIdx.x]; count = seg_start[blockIdx.x + 1] - base; }
-    for (int k = threadIdx.x; k < count; k += blockDim.x) {
-        int ib, jb;          /* birth node, global */
-        double x = 0.0, y = 0.0, e, mx, my;
-        int bx, by;
-        double wxh, wyh;
-        if (IDENTITY) {
-            ib = i0 + (k % PT_TX);
-            jb = j0 + (k / PT_TX);
-            int jl = jb - G.j_begin;
-            if (ib >= G.Nx || jl >= G.ny_loc) continue;
-            const double *rr = rec_row(A, G, jl + G.R);
-            double code = rr[5 * G.Nx + ib];
-            if (code == 0.0) continue;
-            int cg;
-            rec_decode(code, cg, bx, by);
-            e = rr[ib]; mx = rr[G.Nx + ib]; my = rr[2 * G.Nx + ib]; wxh = rr[3 * G.Nx + ib]; wyh = rr[4 * G.Nx + ib];
-        } else {
-            long long pidx = perm[base + k];
-            ib = pij[pidx]; jb = pij[np + pidx];
-            x = pxy[pidx]; y = pxy[np + pidx];
-            e = pch[pidx]; mx = pch[np + pidx]; my = pch[2 * np + pidx];
-            if (!(pm_isfinite(x) && pm_isfinite(y))) continue;
-            index_weight(x, bx, wxh);
-            index_weight(y, by, wyh);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            int ax = c & 1, ay = c >> 1;
-            int ig = ib + bx + ax, jg = jb + by + ay;
-            double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
-            int li = ig - i0 + PT_AP, lj = jg - j0 + PT_AP;
-            if (li >= 0 && li < PT_LX && lj >= 0 && lj < PT_LY) {
-                atomicAdd(&tile[0][lj][li], w * e);
-                atomicAdd(&tile[1][lj][li], w * mx);
-                atomicAdd(&tile[2][lj][li], w * my);
+    const int rounds = (count + (int)blockDim.x - 1) / (int)blockDim.x;
+    for (int rd = 0; rd < rounds; rd++) {                 /* whole waves stay together: the fold below shuffles across lanes */
+        const int k = rd * (int)blockDim.x + (int)threadIdx.x;
+        bool have = k < count;
+        int ib = 0, jb = 0, bx = 0, by = 0;                /* birth node (global), cell offset */
+        double e = 0.0, mx = 0.0, my = 0.0, wxh = 0.0, wyh = 0.0;
+        if (have) {
+            if (IDENTITY) {
+                ib = i0 + (k % PT_TX);
+                jb = j0 + (k / PT_TX);
+                const int jl = jb - G.j_begin;
+                have = ib < G.Nx && jl < G.ny_loc;
+                if (have) {
+                    const double *rr = rec_row(A, G, jl + G.R);
+                    const double code = rr[5 * G.Nx + ib];
+                    have = code != 0.0;
+                    if (have) {
+                        int cg;
+                        rec_decode(code, cg, bx, by);
+                        e = rr[ib]; mx = rr[G.Nx + ib]; my = rr[2 * G.Nx + ib]; wxh = rr[3 * G.Nx + ib]; wyh = rr[4 * G.Nx + ib];
+                    }
+                }
             } else {
-                global_add3(G, A, ig, jg, w * e, w * mx, w * my);
+                const long long pidx = perm[base + k];
+                ib = pij[pidx]; jb = pij[np + pidx];
+                const double x = pxy[pidx], y = pxy[np + pidx];
+                e = pch[pidx]; mx = pch[np + pidx]; my = pch[2 * np + pidx];
+                have = pm_isfinite(x) && pm_isfinite(y);
+                if (have) { index_weight(x, bx, wxh); index_weight(y, by, wyh); }
+            }
+        }
+        /* the four corners in two passes of (lower-x, upper-x) per y row.  The upper-x contributions are rotated by one
+         * lane (lane k offers the upper corner of lane k-1) so that, in the identity layout, it sits next to the lower
+         * corner of the particle one cell to the right — the same node. */
+#pragma unroll
+        for (int ay = 0; ay < 2; ay++) {
+            const double wy = ay ? wyh : 1.0 - wyh;
+            const int jg = jb + by + ay;
+            int klo = -1;
+            double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+            for (int ax = 0; ax < 2; ax++) {
+                const double w = (ax ? wxh : 1.0 - wxh) * wy;
+                double q0 = w * e, q1 = w * mx, q2 = w * my;
+                int ig = ib + bx + ax, jgc = jg;
+                int li = ig - i0 + PT_AP, lj = jgc - j0 + PT_AP;
+                const bool inside = have && li >= 0 && li < PT_LX && lj >= 0 && lj < PT_LY;
+                if (have && !inside) global_add3(G, A, ig, jgc, q0, q1, q2);      /* beyond the apron: rare, straight to HBM */
+                int key = inside ? lj * PT_LX + li : -1;
+                if (ax == 1) {                                /* rotate the upper-x corner to the right-hand neighbour lane */
+                    const int lane = threadIdx.x & 63;
+                    const int kk = __shfl_up(key, 1, 64);
+                    const double r0 = __shfl_up(q0, 1, 64), r1 = __shfl_up(q1, 1, 64), r2 = __shfl_up(q2, 1, 64);
+                    const int k63 = __shfl(key, 63, 64);       /* lane 63's own upper corner wraps to lane 0 */
+                    const double s0 = __shfl(q0, 63, 64), s1 = __shfl(q1, 63, 64), s2 = __shfl(q2, 63, 64);
+                    key = lane ? kk : k63; q0 = lane ? r0 : s0; q1 = lane ? r1 : s1; q2 = lane ? r2 : s2;
+                    /* pair it with this lane's own lower corner of the same y row: two offers per lane, folded one after
+                     * the other — first the rotated upper corner joins the lower one if they agree */
+                }
+                if (ax == 0) { klo = key; l0 = q0; l1 = q1; l2 = q2; }
+                else {
+                    if (key >= 0 && key == klo) { l0 += q0; l1 += q1; l2 += q2; key = -1; }    /* same node: one offer */
+                    /* lower corners (now carrying the neighbour's upper one) */
+                    double f0 = l0, f1 = l1, f2 = l2;
+                    if (wave_fold_runs(klo, f0, f1, f2)) {
+                        const int lj2 = klo / PT_LX, li2 = klo % PT_LX;
+                        atomicAdd(&tile[0][lj2][li2], f0); atomicAdd(&tile[1][lj2][li2], f1); atomicAdd(&tile[2][lj2][li2], f2);
+                    }
+                    /* upper corners that found no partner (different cell offset next door, tile edge) */
+                    if (__ballot(key >= 0)) {
+                        if (wave_fold_runs(key, q0, q1, q2)) {
+                            const int lj2 = key / PT_LX, li2 = key % PT_LX;
+                            atomicAdd(&tile[0][lj2][li2], q0); atomicAdd(&tile[1][lj2][li2], q1); atomicAdd(&tile[2][lj2][li2], q2);
+                        }
+                    }
+                }
             }
         }
     }
@@ -997,6 +1066,14 @@ struct picles_ctx {
             return -10;                                                                        \
         }                                                                                      \
     } while (0)
+
+/* hipStreamQuery without side effects on the sticky last-error state (hipErrorNotReady is not a failure) */
+static bool stream_idle(hipStream_t s)
+{
+    hipError_t e = hipStreamQuery(s);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess;
+}
 
 static int fail(picles_ctx *c, int code, const std::string &m)
 {
@@ -1461,7 +1538,7 @@ static int select_rows(picles_ctx *c, int which, int &r0, int &n0, int &r1, int 
  *    another stream waits for that clear (its atomicMax must not land before it). */
 static int step_prologue(picles_ctx *c, hipStream_t s)
 {
-    if (s != c->stream) {
+    if (s != c->stream && !stream_idle(c->stream)) {     /* an idle context stream has nothing to wait for */
         HIPCHK(c, hipEventRecord(c->ev_ctx, c->stream));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_ctx, 0));
     }
@@ -1697,7 +1774,7 @@ PX_EXPORT int32_t picles_scatter_remesh(picles_ctx *c, void *stream)
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (c->edge_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_edge, 0)); c->edge_pending = false; }
-    if (s != c->stream) {   /* ordered behind whatever the library enqueued on its own stream (see step_prologue) */
+    if (s != c->stream && !stream_idle(c->stream)) {   /* ordered behind whatever the library enqueued on its own stream (see step_prologue) */
         HIPCHK(c, hipEventRecord(c->ev_ctx, c->stream));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_ctx, 0));
     }
@@ -2022,6 +2099,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommFinalize) CommFinalize = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -2045,6 +2123,7 @@ static RcclApi *rccl_api(std::string &err)
 #define RSYM(f) do { api.f = (decltype(api.f))dlsym(h, "nccl" #f); if (!api.f) { err = "librccl lacks nccl" #f; return nullptr; } } while (0)
     RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(CommDestroy); RSYM(GroupStart); RSYM(GroupEnd); RSYM(Send); RSYM(Recv);
     RSYM(GetErrorString);
+    api.CommFinalize = (decltype(api.CommFinalize))dlsym(h, "ncclCommFinalize");     /* optional (NCCL >= 2.14) */
 #undef RSYM
     api.handle = h;
     return &api;
@@ -2089,7 +2168,14 @@ PX_EXPORT int32_t picles_slab_comm_destroy(picles_ctx *c)
     if (!R) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    if (R->comm) R->api->CommDestroy(R->comm);
+    if (R->comm) {
+        const char *mode = getenv("PICLES_RING_TEARDOWN");      /* destroy (default) | finalize | keep — diagnostics */
+        if (mode && !strcmp(mode, "keep")) { /* leave the communicator to process exit */ }
+        else {
+            if (mode && !strcmp(mode, "finalize") && R->api->CommFinalize) R->api->CommFinalize(R->comm);
+            R->api->CommDestroy(R->comm);
+        }
+    }
     if (R->evE) hipEventDestroy(R->evE);
     if (R->evM) hipEventDestroy(R->evM);
     if (R->sE) hipStreamDestroy(R->sE);
@@ -2126,12 +2212,9 @@ PX_EXPORT int32_t picles_slab_comm_init(picles_ctx *c, const void *id128, int32_
         picles_slab_comm_destroy(c);
         return -11;
     }
-    /* the edge stream carries the latency-critical chain (edge rows -> exchange -> the neighbour's next step): highest
-     * priority, so its few workgroups and the RCCL kernels are not queued behind the interior launch */
-    int pr_lo = 0, pr_hi = 0;
-    HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-    HIPCHK(c, hipStreamCreateWithPriority(&R->sE, hipStreamNonBlocking, pr_hi));
-    HIPCHK(c, hipStreamCreateWithPriority(&R->sM, hipStreamNonBlocking, pr_lo));
+    /* (stream priorities were tried for the edge chain and measured slower on MI355X: 0.65 vs 0.46 ms per step at 1448²) */
+    HIPCHK(c, hipStreamCreateWithFlags(&R->sE, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&R->sM, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&R->evE, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&R->evM, hipEventDisableTiming));
     return 0;
@@ -2184,12 +2267,14 @@ PX_EXPORT int32_t picles_slab_run_steps(picles_ctx *c, double dt, int32_t n_step
     c->ring_orders = true;
     struct Off { picles_ctx *c; ~Off() { c->ring_orders = false; } } off{c};
     for (int k = 0; k < n_steps; k++) {
-        /* the context stream (wind-lattice sampler of this step, a flushed scatter) must come after the previous
-         * step's launches on E and M, and this step's launches after it (step_prologue: ev_ctx) */
+        /* the context stream (wind-lattice sampler of this step) must come after the previous step's launches on E and
+         * M, and this step's launches after it (step_prologue: ev_ctx); a flush synchronises the device by itself */
         HIPCHK(c, hipEventRecord(R->evM, R->sM));
-        HIPCHK(c, hipEventRecord(R->evE, R->sE));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, R->evM, 0));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, R->evE, 0));
+        if (c->wind_grid_on) {
+            HIPCHK(c, hipEventRecord(R->evE, R->sE));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, R->evM, 0));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, R->evE, 0));
+        }
         int fused = (flags == PICLES_STEP_ZERO_FIRST) ? picles_begin_fused_step(c, dt) : 1;
         if (fused < 0) return fused;
         if (fused == 1) { int rc = picles_begin_step(c, dt, flags); if (rc) return rc; }

@@ -213,9 +213,10 @@ class SlabModel:
 
     @staticmethod
     def _dist_backend():
+        import sys
+        dist = sys.modules.get("torch.distributed")      # a process group can only exist if somebody imported it
         try:
-            import torch.distributed as dist
-            return dist.get_backend() if dist.is_initialized() else "none"
+            return dist.get_backend() if (dist is not None and dist.is_initialized()) else "none"
         except Exception:
             return "none"
 
