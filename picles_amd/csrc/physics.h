@@ -305,7 +305,7 @@ struct Vec3 {
     double lne, cx, cy;
 };
 
-template <bool FAST, bool METRIC = false, bool DB = false>
+template <bool FAST, bool METRIC = false>
 PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD &W, Vec3 &d, double pc = 0.0)
 {
     const double u = W.u, v = W.v;
@@ -361,8 +361,10 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
             s2 = 0.0;
         else
             s2 = ((P.two_inv_rg2 * crsc) * dotc) * (rc2 * W.invU2);
-        /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned */
-        if (DB || (!FAST && P.deadband2 > 0.0)) {   /* DB: the specialised kernel with the dead band compiled in */
+        /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned.  Only the general-physics
+         * kernels carry it (a run-time test here costs the specialised kernel 2.6 %, measured; a compile-time flavour of it
+         * doubled the kernel count): a context with a dead band runs the general kernels */
+        if (!FAST && P.deadband2 > 0.0) {
             if (crsc * crsc <= P.deadband2 * (W.U2 * c2)) s2 = 0.0;
         }
         Sd = (P.C_phi * aH) * s2;
@@ -389,7 +391,7 @@ struct Seed5 {
     double dL, dcx, dcy, du, dv;
 };
 
-template <bool FAST, bool METRIC, bool DB, int NS>
+template <bool FAST, bool METRIC, int NS>
 PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const WindD &W, double pc,
                     const Seed5 (&seeds)[NS], Vec3 (&df)[NS])
 {
@@ -433,7 +435,7 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     double rU = rc2 * W.invU2;
     double cd = (P.two_inv_rg2 * crsc) * dotc;
     double s2 = calm ? 0.0 : cd * rU;
-    bool dead = (DB || !FAST) && (P.deadband2 > 0.0 && crsc * crsc <= P.deadband2 * (W.U2 * c2));
+    bool dead = !FAST && (P.deadband2 > 0.0 && crsc * crsc <= P.deadband2 * (W.U2 * c2));
     if (dead) s2 = 0.0;
     double Sd = s_dr ? (P.C_phi * aH) * s2 : 0.0;
     double wrS = (wp * P.r_g) * Scg;
@@ -483,7 +485,7 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
 
 /* one attempted Rosenbrock23 step of size h from (z, f0) at absolute time t: returns EEst² (kernel-order norm),
  * un = the new state, f2 = f(un, t+h) (the next step's FSAL), eig = ||J||_inf */
-template <bool FAST, bool STATIC, bool METRIC, bool DB>
+template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z, const Vec3 &f0, double t, double h,
                        double ipx, double ipy, double pc, Vec5 &un, Vec3 &f2, double &eig, PStats &st)
 {
@@ -496,7 +498,7 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     if (!STATIC) seeds[NS - 1] = {0.0, 0.0, 0.0, w.du * P.inv_dtw, w.dv * P.inv_dtw};
     const bool tv = !STATIC && !P.wind_static;   /* a time-varying instantiation may run with static winds: no dT terms then */
     wind_stage<STATIC>(P, w, t, W);
-    rhs3_jvp<FAST, METRIC, DB, NS>(P, z.lne, z.cx, z.cy, W, pc, seeds, dfs);
+    rhs3_jvp<FAST, METRIC, NS>(P, z.lne, z.cx, z.cy, W, pc, seeds, dfs);
     st.rhs += tv ? 4 : 3;
     /* J[r][c] = d f_r / d u_c = dfs[c].r */
     const double J00 = dfs[0].lne, J01 = dfs[1].lne, J02 = dfs[2].lne;
@@ -539,14 +541,14 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     const double sl = PM_FMA(h2, k1.lne, z.lne), sx = PM_FMA(h2, k1.cx, z.cx), sy = PM_FMA(h2, k1.cy, z.cy);
     Vec3 f1;
     wind_stage<STATIC>(P, w, t + h2, W);
-    rhs3<FAST, METRIC, DB>(P, sl, sx, sy, W, f1, pc);
+    rhs3<FAST, METRIC>(P, sl, sx, sy, W, f1, pc);
     const double f1x = sx * ipx, f1y = sy * ipy;
     WSOLVE(f1.lne - k1.lne, f1.cx - k1.cx, f1.cy - k1.cy, f1x - k1.x, f1y - k1.y, k2);
     k2.lne = k2.lne + k1.lne; k2.cx = k2.cx + k1.cx; k2.cy = k2.cy + k1.cy; k2.x = k2.x + k1.x; k2.y = k2.y + k1.y;
     un.lne = PM_FMA(h, k2.lne, z.lne); un.cx = PM_FMA(h, k2.cx, z.cx); un.cy = PM_FMA(h, k2.cy, z.cy);
     un.x = PM_FMA(h, k2.x, z.x); un.y = PM_FMA(h, k2.y, z.y);
     wind_stage<STATIC>(P, w, t + h, W);
-    rhs3<FAST, METRIC, DB>(P, un.lne, un.cx, un.cy, W, f2, pc);
+    rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, f2, pc);
     st.rhs += 2;
     const double f2x = un.cx * ipx, f2y = un.cy * ipy;
 #define ROSB(F2, K2, F1, K1, F0) (((F2) - ROS_E32 * ((K2) - (F1))) - 2.0 * ((K1) - (F0)))
@@ -600,7 +602,7 @@ PM_HD double rms5(double a0, double a1, double a2, double a3, double a4)
 
 /* ode_determine_initdt (Hairer–Wanner), = auto_dt_reset! after every remesh.
  * f0 = (k1, kx, ky) is the RHS at (u0, t). */
-template <bool FAST, bool STATIC, bool METRIC, bool DB = false>
+template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, const Vec3 &k1, double kx, double ky,
                      double ipx, double ipy, double pc, double t, PStats &st)
 {
@@ -629,7 +631,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
     double l1 = PM_FMA(dt0, k1.lne, u0.lne), cx1 = PM_FMA(dt0, k1.cx, u0.cx), cy1 = PM_FMA(dt0, k1.cy, u0.cy);
     Vec3 f1;
     wind_stage<STATIC>(P, w, t + dt0, W);
-    rhs3<FAST, METRIC, DB>(P, l1, cx1, cy1, W, f1, pc);
+    rhs3<FAST, METRIC>(P, l1, cx1, cy1, W, f1, pc);
     st.rhs++;
     double f1x = cx1 * ipx, f1y = cy1 * ipy;
     double S2 = ms5((f1.lne - k1.lne) * r0, (f1.cx - k1.cx) * r1, (f1.cy - k1.cy) * r2,
@@ -655,7 +657,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
 /* AUTO (solver 2, implies TSIT): AutoTsit5(Rosenbrock23()) — after every attempt the AutoSwitch tests
  * |eigen_est·dt_next/3.5068| > 0.9; more than 10 successive positives hand over to Rosenbrock23 (dt·2), more than 3
  * successive negatives hand back (dt/2).  *asw carries (counter << 1 | rosenbrock_active) across model steps. */
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false, bool AUTO = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
 PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, double &dtn,
                          double t_start, double DT, PStats &st, double m11 = 0.0, double m22 = 0.0, double pc = 0.0,
                          int *asw = nullptr)
@@ -671,10 +673,10 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     double tr = 0.0;
     if (STATIC) wind_derive(w.u0, w.v0, W);
     else wind_stage<false>(P, w, t_start, W);
-    rhs3<FAST, METRIC, DB>(P, z.lne, z.cx, z.cy, W, k1, pc);
+    rhs3<FAST, METRIC>(P, z.lne, z.cx, z.cy, W, k1, pc);
     st.rhs++;
     double dt = dtn;
-    if (!(dt > 0.0)) dt = init_dt<FAST, STATIC, METRIC, DB>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, pc, t_start, st);
+    if (!(dt > 0.0)) dt = init_dt<FAST, STATIC, METRIC>(P, w, W, z, k1, z.cx * ipx, z.cy * ipy, ipx, ipy, pc, t_start, st);
     long long iter = 0;
     bool as_fresh = false, as_stiff = false, have_eig = false;
     int as_count = 0;
@@ -706,7 +708,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         Vec5 un;
         double EE2;
         if (AUTO && as_stiff) {
-            EE2 = ros23_try<FAST, STATIC, METRIC, DB>(P, w, W, z, k1, t, h, ipx, ipy, pc, un, k7, eig, st);
+            EE2 = ros23_try<FAST, STATIC, METRIC>(P, w, W, z, k1, t, h, ipx, ipy, pc, un, k7, eig, st);
             eig_nu = eig * eig; eig_nd = 1.0;     /* ||J||_inf */
         } else {
         double gl, gx, gy;      /* stage state (lne, c̄x, c̄y) */
@@ -723,7 +725,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
         }
         wind_stage<STATIC>(P, w, PM_FMA(TT(c2), h, t), W);
-        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k2, pc);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k2, pc);
         if (has2) {
             ax = PM_FMA(TT(a72), gx, ax); ay = PM_FMA(TT(a72), gy, ay);
             ex = PM_FMA(TT(e2), gx, ex); ey = PM_FMA(TT(e2), gy, ey);
@@ -732,21 +734,21 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #define ST3(c) PM_FMA(h, PM_FMA(TT(a32), k2.c, TT(a31) * k1.c), z.c)
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c3), h, t), W);
-        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k3, pc);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k3, pc);
         ax = PM_FMA(TT(a73), gx, ax); ay = PM_FMA(TT(a73), gy, ay);
         ex = PM_FMA(TT(e3), gx, ex); ey = PM_FMA(TT(e3), gy, ey);
         S6ACC(a63);
 #define ST4(c) PM_FMA(h, PM_FMA(TT(a43), k3.c, PM_FMA(TT(a42), k2.c, TT(a41) * k1.c)), z.c)
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c4), h, t), W);
-        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k4, pc);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k4, pc);
         ax = PM_FMA(TT(a74), gx, ax); ay = PM_FMA(TT(a74), gy, ay);
         ex = PM_FMA(TT(e4), gx, ex); ey = PM_FMA(TT(e4), gy, ey);
         S6ACC(a64);
 #define ST5(c) PM_FMA(h, PM_FMA(TT(a54), k4.c, PM_FMA(TT(a53), k3.c, PM_FMA(TT(a52), k2.c, TT(a51) * k1.c))), z.c)
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c5), h, t), W);
-        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k5, pc);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k5, pc);
         ax = PM_FMA(TT(a75), gx, ax); ay = PM_FMA(TT(a75), gy, ay);
         ex = PM_FMA(TT(e5), gx, ex); ey = PM_FMA(TT(e5), gy, ey);
         S6ACC(a65);
@@ -754,14 +756,14 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #define ST6(c) PM_FMA(h, PM_FMA(TT(a65), k5.c, PM_FMA(TT(a64), k4.c, PM_FMA(TT(a63), k3.c, PM_FMA(TT(a62), k2.c, TT(a61) * k1.c)))), z.c)
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
-        rhs3<FAST, METRIC, DB>(P, gl, gx, gy, W, k6, pc);
+        rhs3<FAST, METRIC>(P, gl, gx, gy, W, k6, pc);
         ax = PM_FMA(TT(a76), gx, ax); ay = PM_FMA(TT(a76), gy, ay);
         ex = PM_FMA(TT(e6), gx, ex); ey = PM_FMA(TT(e6), gy, ey);
 #define S72(c) (has2 ? PM_FMA(TT(a72), k2.c, TT(a71) * k1.c) : TT(a71) * k1.c)
 #define ST7(c) PM_FMA(h, PM_FMA(TT(a76), k6.c, PM_FMA(TT(a75), k5.c, PM_FMA(TT(a74), k4.c, PM_FMA(TT(a73), k3.c, S72(c))))), z.c)
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax * ipx, z.x); un.y = PM_FMA(h, ay * ipy, z.y);
-        rhs3<FAST, METRIC, DB>(P, un.lne, un.cx, un.cy, W, k7, pc);
+        rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, k7, pc);
         st.rhs += 6;
         if (AUTO) {   /* Tsit5 inside the composite: eigen_est = ||k7 - k6|| / ||u - g6||, RMS over the 5 components */
             const double g6x = PM_FMA(h, s6x * ipx, z.x), g6y = PM_FMA(h, s6y * ipy, z.y);

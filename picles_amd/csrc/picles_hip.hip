@@ -85,6 +85,8 @@ struct Arrays {
     int *max_reach;          /* max scatter reach of the records in `rec` (read by the pull) */
     int *max_reach_out;      /* ... of the records being written to `rec_out` */
     int *max_reach_total;    /* running maximum since the last reset (slab halos are sized from it) */
+    int *max_reach_next;     /* the counter the NEXT step will write: cleared by this step's advance launches (three counters
+                                rotate — read / written / cleared — so no per-step memset launch sits between the steps) */
     long long n;             /* Nx * ny_loc */
 };
 
@@ -207,7 +209,7 @@ struct StepStats {
     int reach;
 };
 
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool DB = false, bool AUTO = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
 __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
                                                 double &dtn, double t_start, double DT, StepStats &S,
                                                 double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
@@ -215,7 +217,7 @@ __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w,
     int status = PICLES_ST_STEPPED;
     if (on) {
         S.adv = 1;
-        integrate_dp5<FAST, STATIC, METRIC, TSIT, DB, AUTO>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc, asw);
+        integrate_dp5<FAST, STATIC, METRIC, TSIT, AUTO>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc, asw);
         status |= S.st.status;
     } else {
         double u, v;
@@ -313,6 +315,7 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
             atomicMax(A.max_reach_out, m_reach);
         if (m_reach > __hip_atomic_load(A.max_reach_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(A.max_reach_total, m_reach);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *A.max_reach_next = 0;     /* nobody reads or writes it during this step */
     }
 }
 
@@ -364,8 +367,8 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         Wind w = load_wind(P, A, t);
         int status;
         int asw = AUTO ? A.asw[t] : 0;
-        if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, false, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
-        else status = advance_particle<FAST, STATIC, false, TSIT, false, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
+        if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
+        else status = advance_particle<FAST, STATIC, false, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
         if (AUTO) A.asw[t] = asw;
         A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
         A.on[t] = (unsigned char)on;
@@ -702,7 +705,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
 /* Occupancy: the explicit pairs fit 168 VGPRs = three waves per SIMD; the auto-switching flavour (Rosenbrock23 peaks at
  * ~220 live registers) is built for two waves with no scratch — measured equal to the spilling three-wave build, and a
  * two-phase split was measured slower (profiles/r2_two_phase_auto_experiment.md). */
-template <bool FAST, bool TSIT, bool DB, bool STATIC, bool METRIC, bool AUTO>
+template <bool FAST, bool TSIT, bool STATIC, bool METRIC, bool AUTO>
 __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 3 : 2) k_step(KParams P, GridP G, Arrays A, double t_prev, double DT_prev,
                                                 double t_start, double DT, int r0, int n0, int r1, int n1)
 {
@@ -728,8 +731,8 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 3 : 2) k_step(KParams P
             unsigned int rs = S.reseeds;
             S.reseeds = 0;
             int status;
-            if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, DB, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
-            else status = advance_particle<FAST, STATIC, false, TSIT, DB, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
+            if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
+            else status = advance_particle<FAST, STATIC, false, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
             if (AUTO) A.asw[t] = asw;
             S.reseeds += rs;
             A.qold[t] = qold;
@@ -1010,14 +1013,13 @@ struct picles_ctx {
     hipStream_t stream;
     hipEvent_t ev_edge;
     hipEvent_t ev_ctx = nullptr;        /* "everything enqueued on the context stream so far": caller streams wait for it */
-    hipEvent_t ev_prologue = nullptr;   /* the per-step clear of the reach counter, recorded on the step's first stream */
-    hipStream_t prologue_stream = nullptr;
     bool edge_pending = false;
     bool step_fresh = false;
     struct SlabRing *ring = nullptr;    /* native RCCL slab ring (picles_slab_*) */
     /* record buffer pair: rec_buf[cur] belongs to the step in flight / last completed advance */
     double *rec_buf[2] = {nullptr, nullptr};
-    int *mr_buf[2] = {nullptr, nullptr};
+    int *mr_buf[3] = {nullptr, nullptr, nullptr};     /* reach counters: one read (previous step), one written, one being cleared */
+    int mr_w = 0;                                      /* index of the counter the step in flight writes */
     int cur = 0;
     /* fused stepping: the last advance's records still await their scatter + remesh */
     bool fuse_steps = true;
@@ -1122,8 +1124,11 @@ static Arrays arrays_for(picles_ctx *c, int read_buf, int write_buf)
     Arrays A = c->A;
     A.rec = c->rec_buf[read_buf];
     A.rec_out = c->rec_buf[write_buf];
-    A.max_reach = c->mr_buf[read_buf];
-    A.max_reach_out = c->mr_buf[write_buf];
+    /* reach counters rotate with the steps, independently of the record pair: a launch that scatters the records it has just
+     * written (read_buf == write_buf: k_scatter after k_advance) reads the counter of the step in flight */
+    A.max_reach = c->mr_buf[read_buf == write_buf ? c->mr_w : (c->mr_w + 2) % 3];
+    A.max_reach_out = c->mr_buf[c->mr_w];
+    A.max_reach_next = c->mr_buf[(c->mr_w + 1) % 3];
     return A;
 }
 
@@ -1270,7 +1275,6 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->ev_ctx, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&c->ev_prologue, hipEventDisableTiming));
     Arrays &A = c->A;
     memset(&A, 0, sizeof(A));
     A.n = n;
@@ -1282,9 +1286,11 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     CK(hipMalloc(&A.cnt, NSLOTS * sizeof(DevCounters)));
     CK(hipMalloc(&A.max_reach_total, sizeof(int)));
     CK(hipMemset(A.max_reach_total, 0, sizeof(int)));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         CK(hipMalloc(&c->mr_buf[k], sizeof(int)));
         CK(hipMemset(c->mr_buf[k], 0, sizeof(int)));
+    }
+    for (int k = 0; k < 2; k++) {
         CK(hipMalloc(&c->rec_buf[k], rec_bytes(c)));
         CK(hipMemset(c->rec_buf[k], 0, rec_bytes(c)));
     }
@@ -1313,7 +1319,8 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
     hipFree(A.cnt); hipFree(A.max_reach_total); hipFree(c->d_mask);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
-    for (int k = 0; k < 2; k++) { hipFree(c->rec_buf[k]); hipFree(c->mr_buf[k]); }
+    for (int k = 0; k < 2; k++) hipFree(c->rec_buf[k]);
+    for (int k = 0; k < 3; k++) hipFree(c->mr_buf[k]);
     for (auto p : c->store_dev) hipFree(p);
     for (auto p : c->store_host) hipHostFree(p);
     for (auto e : c->store_ready) hipEventDestroy(e);
@@ -1329,7 +1336,6 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     for (auto &e : c->ev_free) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (c->ev_edge) hipEventDestroy(c->ev_edge);
     if (c->ev_ctx) hipEventDestroy(c->ev_ctx);
-    if (c->ev_prologue) hipEventDestroy(c->ev_prologue);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1464,9 +1470,11 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
     }
     c->pending = false;
     c->cur = 0;
+    c->mr_w = 0;
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, hipMemsetAsync(c->rec_buf[k], 0, rec_bytes(c), c->stream));
         HIPCHK(c, hipMemsetAsync(c->mr_buf[k], 0, sizeof(int), c->stream));
+        if (k == 0) HIPCHK(c, hipMemsetAsync(c->mr_buf[2], 0, sizeof(int), c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
     HIPCHK(c, hipMemsetAsync(c->A.max_reach_total, 0, sizeof(int), c->stream));
@@ -1503,6 +1511,7 @@ PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
     c->step_flags = flags;
     c->edge_pending = false;
     c->cur ^= 1;            /* this step's records go to (and are scattered from) rec_buf[cur] */
+    c->mr_w = (c->mr_w + 1) % 3;
     c->step_fresh = true;   /* the first advance_rows of the step clears max_reach on ITS stream */
     if (c->wind_grid_on) {
         HIPCHK(c, hipSetDevice(c->device));
@@ -1530,25 +1539,15 @@ static int select_rows(picles_ctx *c, int which, int &r0, int &n0, int &r1, int 
     return 0;
 }
 
-/* Launches of one step may come on caller-provided streams.  Two orderings are the library's business:
- *  - whatever it enqueued on its own stream before (the scatter + remesh of a flushed step, a wind-lattice
- *    sample, the seed) must be complete before a caller-stream kernel reads it: the caller stream waits for an
- *    event recorded on the context stream;
- *  - the first launch of a step clears the step's reach counter on ITS stream; a launch of the same step on
- *    another stream waits for that clear (its atomicMax must not land before it). */
+/* Launches of one step may come on caller-provided streams.  Whatever the library enqueued on its own stream before (the
+ * scatter + remesh of a flushed step, a wind-lattice sample, the seed) must be complete before a caller-stream kernel reads
+ * it: the caller stream waits for an event recorded on the context stream.  (The step's reach counter needs no clearing
+ * here: three counters rotate and the previous step's launches cleared this one — Arrays::max_reach_next.) */
 static int step_prologue(picles_ctx *c, hipStream_t s)
 {
     if (s != c->stream && !stream_idle(c->stream)) {     /* an idle context stream has nothing to wait for */
         HIPCHK(c, hipEventRecord(c->ev_ctx, c->stream));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_ctx, 0));
-    }
-    if (c->step_fresh) {
-        HIPCHK(c, hipMemsetAsync(c->mr_buf[c->cur], 0, sizeof(int), s));
-        HIPCHK(c, hipEventRecord(c->ev_prologue, s));
-        c->prologue_stream = s;
-        c->step_fresh = false;
-    } else if (s != c->prologue_stream) {
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_prologue, 0));
     }
     return 0;
 }
@@ -1578,8 +1577,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
         if (c->A.pc) LAUNCH_ADV(false, false, true);   /* per-node metric: the general code path */
         else if (fast && P.wind_static) LAUNCH_ADV(true, true, false);
         else if (fast) LAUNCH_ADV(true, false, false);
-        else if (P.wind_static) LAUNCH_ADV(false, true, false);
-        else LAUNCH_ADV(false, false, false);
+        else LAUNCH_ADV(false, false, false);          /* general physics; static winds are the du = dv = 0 case of the same code (same bits) */
 #undef LAUNCH_ADV2
 #undef LAUNCH_ADV
     }
@@ -1597,7 +1595,7 @@ static bool step_fusable(const picles_ctx *c, int flags)
 {
     if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps) return false;
     const KParams &P = c->P;
-    const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
+    const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
     /* the time-varying-wind and per-node-metric flavours of the fused kernel exist for the specialised physics */
     if (c->wind_grid_on) return fast;
     if (c->A.pc) return fast && P.wind_static != 0;
@@ -1617,42 +1615,27 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     if ((rc = step_prologue(c, s))) return rc;
     const KParams &P = c->P;
     Arrays A = arrays_for(c, c->cur ^ 1, c->cur);
-    /* specialised variant: every physics switch on and n = 2 (all reference scripts); the opt-in dead band is a
-     * compile-time flavour of it */
-    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2;
-    bool db = P.deadband2 > 0.0;
+    /* specialised variant: every physics switch on and n = 2 (all reference scripts) */
+    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
     dim3 grid(nblocks(nt, 256)), block(256);
     timing_begin(c, s, 0);
-#define LAUNCH_STEP(F, T, D, S, M) LAUNCH_STEP6(F, T, D, S, M, false)
-#define LAUNCH_STEP6(F, T, D, S, M, AU) hipLaunchKernelGGL((k_step<F, T, D, S, M, AU>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
-    if (fast && P.solver == 2) {   /* auto-switching solver: dead band x static winds x per-node metric */
-        const int key = (db ? 4 : 0) | (P.wind_static ? 2 : 0) | (c->A.pc ? 1 : 0);
+#define LAUNCH_STEP(F, T, S, M, AU) hipLaunchKernelGGL((k_step<F, T, S, M, AU>), grid, block, 0, s, c->P, c->G, A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1)
+    if (fast) {     /* solver (DP5 / Tsit5 / auto-switching) x static winds x per-node metric: 12 flavours */
+        const int key = (P.solver == 2 ? 8 : (P.solver ? 4 : 0)) | (P.wind_static ? 2 : 0) | (c->A.pc ? 1 : 0);
         switch (key) {
-#define CASE_AUTO(k, D, S, M) case k: LAUNCH_STEP6(true, true, D, S, M, true); break;
-            CASE_AUTO(0, false, false, false) CASE_AUTO(1, false, false, true) CASE_AUTO(2, false, true, false) CASE_AUTO(3, false, true, true)
-            CASE_AUTO(4, true, false, false)  CASE_AUTO(5, true, false, true)  CASE_AUTO(6, true, true, false)  CASE_AUTO(7, true, true, true)
-#undef CASE_AUTO
-        }
-    }
-    else if (fast) {     /* specialised physics: solver x dead band x static winds x per-node metric */
-        const int key = (P.solver ? 8 : 0) | (db ? 4 : 0) | (P.wind_static ? 2 : 0) | (c->A.pc ? 1 : 0);
-        switch (key) {
-#define CASE_STEP(k, T, D, S, M) case k: LAUNCH_STEP(true, T, D, S, M); break;
-            CASE_STEP(0, false, false, false, false) CASE_STEP(1, false, false, false, true)
-            CASE_STEP(2, false, false, true, false)  CASE_STEP(3, false, false, true, true)
-            CASE_STEP(4, false, true, false, false)  CASE_STEP(5, false, true, false, true)
-            CASE_STEP(6, false, true, true, false)   CASE_STEP(7, false, true, true, true)
-            CASE_STEP(8, true, false, false, false)  CASE_STEP(9, true, false, false, true)
-            CASE_STEP(10, true, false, true, false)  CASE_STEP(11, true, false, true, true)
-            CASE_STEP(12, true, true, false, false)  CASE_STEP(13, true, true, false, true)
-            CASE_STEP(14, true, true, true, false)   CASE_STEP(15, true, true, true, true)
+#define CASE_STEP(k, T, S, M, AU) case k: LAUNCH_STEP(true, T, S, M, AU); break;
+            CASE_STEP(0, false, false, false, false) CASE_STEP(1, false, false, true, false)
+            CASE_STEP(2, false, true, false, false)  CASE_STEP(3, false, true, true, false)
+            CASE_STEP(4, true, false, false, false)  CASE_STEP(5, true, false, true, false)
+            CASE_STEP(6, true, true, false, false)   CASE_STEP(7, true, true, true, false)
+            CASE_STEP(8, true, false, false, true)   CASE_STEP(9, true, false, true, true)
+            CASE_STEP(10, true, true, false, true)   CASE_STEP(11, true, true, true, true)
 #undef CASE_STEP
         }
     }
-    else if (P.solver) LAUNCH_STEP(false, true, false, true, false);      /* general physics: static winds, Cartesian (step_fusable) */
-    else LAUNCH_STEP(false, false, false, true, false);
+    else if (P.solver) LAUNCH_STEP(false, true, true, false, false);      /* general physics: static winds, Cartesian (step_fusable) */
+    else LAUNCH_STEP(false, false, true, false, false);
 #undef LAUNCH_STEP
-#undef LAUNCH_STEP6
     timing_end(c, s);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1702,6 +1685,7 @@ PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
     c->step_flags = PICLES_STEP_ZERO_FIRST;
     c->edge_pending = false;
     c->cur ^= 1;
+    c->mr_w = (c->mr_w + 1) % 3;
     c->step_fresh = true;
     return 0;
 }
@@ -1898,7 +1882,7 @@ PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
     int rc = d2h(c, d.data(), c->A.cnt, NSLOTS * sizeof(DevCounters));
     if (rc) return rc;
     int mr = 0, mrt = 0;
-    if ((rc = d2h(c, &mr, c->mr_buf[c->cur], sizeof(int)))) return rc;
+    if ((rc = d2h(c, &mr, c->mr_buf[c->mr_w], sizeof(int)))) return rc;
     if ((rc = d2h(c, &mrt, c->A.max_reach_total, sizeof(int)))) return rc;
     memset(out, 0, sizeof(*out));
     for (const DevCounters &k : d) {

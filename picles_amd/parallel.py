@@ -31,6 +31,23 @@ def slab_rows(Ny: int, world: int, rank: int):
     return j0, j0 + base + (1 if rank < rem else 0)
 
 
+_uid_round = [0]
+
+
+def share_unique_id(uid, rank: int) -> bytes:
+    """hand rank 0's 128-byte ncclUniqueId to every rank through the key-value store of the default process group (the
+    rendezvous TCP store: no collective, no device traffic — the only thing torch.distributed does for the native ring).
+    Called collectively; every call uses a fresh key."""
+    import torch.distributed as dist
+    store = dist.distributed_c10d._get_default_store()
+    key = f"picles_slab_uid_{_uid_round[0]}"
+    _uid_round[0] += 1
+    if rank == 0:
+        store.set(key, bytes(uid))
+        return bytes(uid)
+    return bytes(store.get(key))          # blocks until rank 0 has published it
+
+
 class _DevBlock:
     """exposes a raw device pointer to torch via the CUDA array interface"""
 
@@ -227,10 +244,7 @@ class SlabModel:
         try:
             uid = b.slab_unique_id() if rank == 0 else None
             if world > 1:
-                import torch.distributed as dist
-                box = [uid]
-                dist.broadcast_object_list(box, src=0)
-                uid = box[0]
+                uid = share_unique_id(uid, rank)
             b.slab_comm_init(uid, rank, world)
             self.native = True
         except K.PiclesError as e:

@@ -60,8 +60,9 @@ def ODEParameters(r_g=0.85, q=-0.25, g=9.81):
 @dataclass
 class ODESettings:
     """particle_waves_v5.jl:34-75 (same field names and defaults; `solver` is the NAME of the
-    OrdinaryDiffEq algorithm: "DP5", "Tsit5", or the reference default "AutoTsit5(Rosenbrock23())",
-    which runs as Tsit5 here — the stiff Rosenbrock23 fallback is not implemented)"""
+    OrdinaryDiffEq algorithm: "DP5", "Tsit5", or the reference default "AutoTsit5(Rosenbrock23())" —
+    Tsit5 with OrdinaryDiffEq's AutoSwitch stiffness test and a Rosenbrock23 fallback on an exact
+    hand-written Jacobian, all inside the kernel (picles_ode.solver = 2))"""
     Parameters: dict
     log_energy_minimum: float
     saving_step: float

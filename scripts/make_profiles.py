@@ -17,9 +17,14 @@ shutil.copy(pick(f"{R}_stats", "kernel_stats.csv", "k_step"), out / f"{R}_bench_
 shutil.copy(pick(f"{R}_stats_generic", "kernel_stats.csv", "k_step"), out / f"{R}_bench_generic_kernel_stats.csv")
 shutil.copy(G / f"{R}_bench.json", out / f"{R}_bench.json")
 shutil.copy(G / f"{R}_bench_generic.json", out / f"{R}_bench_generic.json")
-for extra in (f"{R}_bench_generic_deadband.json", f"{R}_bench_solvers.jsonl", f"{R}_baseline_configs.jsonl"):
+for extra in (f"{R}_bench_generic_deadband.json", f"{R}_bench_solvers.jsonl", f"{R}_baseline_configs.jsonl",
+              f"{R}_bench_ring_of_one_1448.json", f"{R}_bench_1448.json", f"{R}_bench_ring_of_one_4096.json", f"{R}_bench_gloo2.json"):
     if (G / extra).exists():
         shutil.copy(G / extra, out / extra)
+try:
+    shutil.copy(pick(f"{R}_stats_ring", "kernel_stats.csv", "k_step"), out / f"{R}_ring_of_one_kernel_stats.csv")
+except SystemExit:
+    pass
 
 def agg(d):
     rows = list(csv.DictReader(open(pick(d, "counter_collection.csv", "k_step"))))
@@ -59,10 +64,21 @@ lines += ["", f"Reading: the fused `{dom}` (one launch per model step) keeps the
           f"chip sustains that is ≈{tot/5e12*1e3:.2f} ms of the ≈{launch_ms:.2f} ms launch. Before fusion (k_advance + k_scatter) the step moved 5.5 GB."]
 ring = out / f"{R}_ring_of_one_kernel_stats.csv"
 if ring.exists():
+    rows = {r["Name"].split("(")[0].replace("void ", ""): r for r in csv.DictReader(open(ring))}
+    def J(f):
+        return json.loads([l for l in open(out / f) if l.startswith("{")][0])
     lines += ["", "## Ring of one (`bench.py --ring-of-one --grid-n 1448`, the per-rank size of an eighth of the BASELINE box)", "",
-              f"`profiles/{ring.name}` (rocprofv3 --kernel-trace --stats): per model step two `k_step` launches (edge rows ≈36 µs,",
-              "interior rows ≈400 µs) and one `rcclGenericKernel` (the grouped send/recv of the two halo blocks; ≈0.26 ms wall while it waits for its",
-              "peer, concurrent with the interior launch on the other stream). 0.419 ms/step against 0.4125 ms for the same grid without the exchange."]
+              f"`profiles/{ring.name}` (rocprofv3 --kernel-trace --stats) — the native slab ring (`picles_slab_run_steps`), context in slab mode so",
+              "that the received ghost rows are consumed.  Per kernel: calls, average / min / max [µs]:", ""]
+    for k, r in rows.items():
+        if k.startswith("k_step") or "rccl" in k.lower() or "nccl" in k.lower():
+            lines.append(f"* `{k}`: {r['Calls']} calls, {float(r['AverageNs'])/1e3:.1f} / {float(r['MinNs'])/1e3:.1f} / {float(r['MaxNs'])/1e3:.1f}")
+    try:
+        a, b = J(f"{R}_bench_ring_of_one_1448.json"), J(f"{R}_bench_1448.json")
+        lines += ["", f"{a['ms_per_step']:.4f} ms/step with the ring against {b['ms_per_step']:.4f} ms for the same grid as one plain context; host side of the step loop "
+                      f"{a['config']['host_enqueue_us_per_step']:.1f} µs per step (one C call for all {a['steps']} steps)."]
+    except Exception as e:
+        lines += ["", f"(bench lines missing: {e})"]
 (out / f"{R}_pmc_summary.md").write_text("\n".join(lines) + "\n")
 json.dump({"config": {"n": 4096, "winds": [10.0, 10.0]}, "dominant": dom, "kernels": res}, open(out / f"{R}_pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines))

@@ -132,3 +132,27 @@ def test_slab_rows_partition():
         assert rows[0][0] == 0 and rows[-1][1] == Ny
         assert all(rows[k][1] == rows[k + 1][0] for k in range(w - 1))
         assert max(b - a for a, b in rows) - min(b - a for a, b in rows) <= 1
+
+
+def _uid_worker(rank, world, port, outdir):
+    sys.path.insert(0, str(ROOT))
+    from picles_amd.parallel import share_unique_id
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    got = []
+    for k in range(3):          # several rings in one job (bench.py builds more than one model): a fresh key each time
+        uid = bytes([(7 * k + i) % 256 for i in range(128)]) if rank == 0 else None
+        got.append(share_unique_id(uid, rank))
+    np.save(os.path.join(outdir, f"uid{rank}.npy"), np.frombuffer(b"".join(got), dtype=np.uint8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unique_id_reaches_every_rank_through_the_store(tmp_path):
+    """the one thing torch.distributed does for the native slab ring: rank 0's 128-byte ncclUniqueId reaches all ranks
+    through the rendezvous store (no collective)"""
+    world = 3
+    mp.spawn(_uid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "uid0.npy")
+    assert ref.size == 3 * 128 and not np.array_equal(ref[:128], ref[128:256])
+    for r in range(1, world):
+        assert np.array_equal(np.load(tmp_path / f"uid{r}.npy"), ref)
