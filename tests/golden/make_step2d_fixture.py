@@ -76,8 +76,9 @@ def id_constants(r_g=0.85, c_D=2e-3, c_beta=4e-2, c_e=1.3e-6, c_alpha=11.8, r_w=
     return dict(r_g=r_g, c_D=c_D, c_beta=c_beta, c_e=c_e, c_alpha=c_alpha, C_e=C_e, gamma=gamma, q=q, p=p, n=n)
 
 
-def make_rhs(uf, vf, idc, C_alpha, C_phi, inv_dx, inv_dy, sw):
-    """particle_system(dz, z, params, t) for one node; uf(t), vf(t) are the node winds"""
+def make_rhs(uf, vf, idc, C_alpha, C_phi, inv_dx, inv_dy, sw, pc=0.0):
+    """particle_system(dz, z, params, t) for one node; uf(t), vf(t) are the node winds; M = diag(inv_dx, inv_dy) is the node's
+    ProjetionKernel, pc the coefficient of its PropagationCorrection (S_sphere = c̄_x * pc, :521-530)"""
     r_g, C_e, p, n, q = idc["r_g"], idc["C_e"], idc["p"], idc["n"], idc["q"]
     e_T = math.sqrt(idc["c_e"] * idc["c_alpha"] ** (-p / q) / (idc["gamma"] * idc["c_beta"] * idc["c_D"]) ** (1 / n))
 
@@ -103,9 +104,10 @@ def make_rhs(uf, vf, idc, C_alpha, C_phi, inv_dx, inv_dy, sw):
             UG = U * sg
             s2 = 0.0 if UG == 0 else (2 / UG ** 2) * (u * v * (2 * gy ** 2 - sg ** 2) - gx * gy * (2 * v ** 2 - U ** 2))
             Sd = (min(U / (2.0 * sg), 500.0) if sg != 0 else 500.0) ** 2 * C_phi * H * s2
+        Ss = cx * pc
         return [wp * r_g * Scg + wp * (It - Dt),
-                -cx * wp * r_g * Scg + cy * Sd,
-                -cy * wp * r_g * Scg - cx * Sd,
+                -cx * wp * r_g * Scg + cy * Sd + cy * Ss,
+                -cy * wp * r_g * Scg - cx * Sd - cx * Ss,
                 cx * inv_dx if sw["propagation"] else 0.0,
                 cy * inv_dy if sw["propagation"] else 0.0]
     return f
@@ -164,12 +166,44 @@ def make_boundaries(mask, per_x, per_y):
 
 
 # ---------------------------------------------------------------- the model
+# ---------------------------------------------------------------- SphericalGrid.jl, spherical_grid_corrections.jl
+def spherical_mesh(xmin, xmax, Nx, ymin, ymax, Ny):
+    """node lon / lat in degrees; per node the diagonal of ProjetionKernel (SphericalGrid.jl:225-237, with the reference's
+    `cos.(Gi.dy * pi / 180)` as written — dy is in metres there) and the SphericalPropagationCorrection coefficient
+    (spherical_grid_corrections.jl:3-21)"""
+    x = xmin + (xmax - xmin) / (Nx - 1) * np.arange(Nx)
+    y = ymin + (ymax - ymin) / (Ny - 1) * np.arange(Ny)
+    XX, YY = np.meshgrid(x, y, indexing="ij")
+    dxd = np.zeros(XX.shape)                       # cal_dx_degree :25-31
+    dxd[1:-1, :] = (XX[2:, :] - XX[:-2, :]) / 2
+    dxd[0, :] = XX[1, :] - XX[0, :]
+    dxd[-1, :] = XX[-1, :] - XX[-2, :]
+    dyd = np.zeros(YY.shape)                       # cal_dy_degree :33-39
+    dyd[:, 1:-1] = (YY[:, 2:] - YY[:, :-2]) / 2
+    dyd[:, 0] = YY[:, 1] - YY[:, 0]
+    dyd[:, -1] = YY[:, -1] - YY[:, -2]
+    R = 6371.0e3
+    dxm = dxd * np.pi / 180 * (R * np.cos(YY * np.pi / 180))      # cal_dx_meters :52-57
+    dym = dyd * np.pi / 180 * R                                   # cal_dy_meters :70-73
+    cos_lat = np.cos(dym * np.pi / 180)
+    m11, m22 = 1 / (cos_lat * dxm), 1 / dym
+    sg = np.sign(YY)
+    pc = (sg * np.minimum(sg * np.tan(np.deg2rad(YY)), 60.0)) / 6.3710e6
+    return x, y, m11, m22, pc
+
+
 class Model:
     def __init__(self, Nx, Ny, dx, dy, per_x, per_y, ocean, winds, periodic_boundary, C_phi, sw, DT, timestep,
-                 lne_max, wind_min_sq=4.0):
+                 lne_max, wind_min_sq=4.0, mesh=None, defaults=None):
         self.Nx, self.Ny, self.dx, self.dy, self.per_x, self.per_y = Nx, Ny, dx, dy, per_x, per_y
         self.x = np.arange(Nx) * dx
         self.y = np.arange(Ny) * dy
+        self.m11 = np.full((Nx, Ny), 1 / dx) if mesh is None else mesh[2]
+        self.m22 = np.full((Nx, Ny), 1 / dy) if mesh is None else mesh[3]
+        self.pc = np.zeros((Nx, Ny)) if mesh is None else mesh[4]
+        if mesh is not None:
+            self.x, self.y = mesh[0], mesh[1]
+        self.defaults = defaults            # ParticleDefaults (lne, c̄x, c̄y) or None = "wind_sea"
         self.winds, self.DT, self.timestep = winds, DT, timestep
         self.idc = id_constants()
         self.C_alpha, self.C_phi, self.sw = -1.41, C_phi, sw
@@ -192,6 +226,11 @@ class Model:
                 if self.mask[i, j] == 0:
                     continue
                 u, v = self.wind(i, j, 0.0)
+                if self.defaults is not None:          # InitParticleValues: fixed defaults, particle on (core_2D.jl:281-284)
+                    self.z[i, j] = [self.defaults[0], self.defaults[1], self.defaults[2], 0.0, 0.0]
+                    self.on[i, j] = True
+                    self.State[i, j] = particle_to_charge(self.z[i, j])
+                    continue
                 if math.sqrt(u ** 2 + v ** 2) > math.sqrt(2):
                     w = get_initial_windsea(u, v, timestep)
                     self.on[i, j] = True
@@ -206,6 +245,9 @@ class Model:
         return float(self.winds[0](self.x[i], self.y[j], t)), float(self.winds[1](self.x[i], self.y[j], t))
 
     def reseed(self, uv, DT):
+        """ResetParticleValues (core_2D.jl:307-343): the windsea of the given wind, or the fixed default particle"""
+        if self.defaults is not None:
+            return [self.defaults[0], self.defaults[1], self.defaults[2], 0.0, 0.0]
         w = get_initial_windsea(uv[0], uv[1], DT)
         return [w["lne"], w["cx"], w["cy"], 0.0, 0.0]
 
@@ -215,7 +257,7 @@ class Model:
         z = list(self.z[i, j])
         if self.on[i, j]:
             f = make_rhs(lambda t: self.wind(i, j, t)[0], lambda t: self.wind(i, j, t)[1], self.idc, self.C_alpha,
-                         self.C_phi, 1 / self.dx, 1 / self.dy, self.sw)
+                         self.C_phi, self.m11[i, j], self.m22[i, j], self.sw, pc=self.pc[i, j])
             sol = solve_ivp(f, (t0, t0 + DT), z, method="DOP853", rtol=1e-12, atol=1e-14)
             assert sol.success
             z = [float(a) for a in sol.y[:, -1]]
@@ -306,12 +348,50 @@ CASES = {
 }
 STEPS = (1, 3, 6)
 
+# lon / lat mesh (tests/T03_PIC_sphere_aqua.jl:36-175 in miniature): per-node projection M and great-circle term PC, a fixed
+# default particle (ODEinit_type = ParticleDefaults, boundary_type "same"), a Gaussian wind blob, the same land mask
+# 0.3° cells at 60-66°N: a particle crosses a quarter of a cell per hour and the great-circle term turns c̄ by ~2e-2 rad over the run,
+# so a wrong M or PC is far outside the 1e-3 tolerance of this (non-stiff, C_phi = 1.81e-5) case
+SPHERE = dict(xmin=0.0, xmax=6.9, ymin=60.0, ymax=65.7, DT=3600.0, timestep=1200.0, C_phi=1.81e-5, periodic_boundary=False,
+              lne_max=math.log(27), sw=ALL_ON, default_wind=(-3.0, 0.5))
+
+
+def sphere_winds():
+    def blob(x, y):
+        return np.exp(-(x - 3.5) ** 2 / 1.8 ** 2) * np.exp(-(y - 63.0) ** 2 / 1.4 ** 2)
+
+    def u(x, y, t):
+        return -14.0 * blob(x, y) + 0 * t
+
+    def v(x, y, t):
+        return 4.0 * blob(x, y) + 0 * t
+    return u, v
+
+
+def sphere_defaults():
+    # the windsea of a 3 m/s wind: well above the minimal_state thresholds (those are the windsea of a 1 m/s wind; the
+    # reference's sphere script seeds exactly AT the threshold, where the on/off pattern of the calm regions is decided by rounding)
+    w = get_initial_windsea(SPHERE["default_wind"][0], SPHERE["default_wind"][1], SPHERE["timestep"])
+    return (w["lne"], w["cx"], w["cy"])
+
+
+def build(name):
+    if name == "sphere":
+        c = SPHERE
+        mesh = spherical_mesh(c["xmin"], c["xmax"], NX, c["ymin"], c["ymax"], NY)
+        return Model(NX, NY, 1.0, 1.0, True, False, ocean_mask(), sphere_winds(), c["periodic_boundary"], c["C_phi"], c["sw"],
+                     c["DT"], c["timestep"], c["lne_max"], mesh=mesh, defaults=sphere_defaults())
+    c = CASES[name]
+    u, v = winds_space(c["dx"], c["dy"], tfac=c["tfac"])
+    return Model(NX, NY, c["dx"], c["dy"], True, False, ocean_mask(), (u, v), c["periodic_boundary"], c["C_phi"], c["sw"],
+                 c["DT"], c["timestep"], c["lne_max"])
+
 
 def main():
-    for name, c in CASES.items():
-        u, v = winds_space(c["dx"], c["dy"], tfac=c["tfac"])
-        m = Model(NX, NY, c["dx"], c["dy"], True, False, ocean_mask(), (u, v), c["periodic_boundary"], c["C_phi"], c["sw"],
-                  c["DT"], c["timestep"], c["lne_max"])
+    import sys
+    names = sys.argv[1:] or (list(CASES) + ["sphere"])
+    for name in names:
+        m = build(name)
         out = dict(state0=m.State.copy(), mask=m.mask.astype(np.int8), on0=m.on.copy(),
                    minimal_state=np.array(m.minimal_state))
         for k in range(1, max(STEPS) + 1):
