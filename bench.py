@@ -115,6 +115,7 @@ def main():
                     help="halo rows = scatter reach the slabs cover (the box reaches 2 cells after ~45 steps; ignored for one GPU)")
     ap.add_argument("--atomic", action="store_true", help="LDS-tiled atomic push scatter instead of the pull")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="diagnostic: no HIP events around the launches (roofline fields become meaningless)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (generic wind direction, default solver)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -195,7 +196,7 @@ def main():
         model.run_steps(cfg.Δt, W_, flags)
         model.sync()
         model.backend.reset_counters()
-        model.backend.enable_timing(True)
+        model.backend.enable_timing(not args.no_events)
         barrier(model)
         t0 = time.perf_counter()
         model.run_steps(cfg.Δt, K_, flags)
@@ -242,7 +243,7 @@ def main():
         launches_per_step = max(tim["advance_launches"], 1) / Ksteps
         # dominant kernel: k_advance.  algorithmic bytes per launch = B_ALG × particles a launch advances
         per_launch = n_local / launches_per_step
-        achieved = B_ALG * per_launch / (adv_ms * 1e-3) / 1e9
+        achieved = B_ALG * per_launch / (adv_ms * 1e-3) / 1e9 if adv_ms > 0 else 0.0
         rhs_per_ps = rhs_total / (n_total * Ksteps)
         tflops = rhs_total * FLOP_PER_RHS / elapsed / 1e12
         traffic, valu_busy, valu_per_wave = measured_traffic(args, world)

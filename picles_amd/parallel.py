@@ -241,6 +241,23 @@ class SlabModel:
         """rank 0 draws the ncclUniqueId, torch.distributed broadcasts the 128 bytes, every rank joins the ring"""
         import sys
         b = self.backend
+        if world > 1:
+            # pre-flight, BEFORE anybody enters the blocking ncclCommInitRank: can every rank bind RCCL at all?  (a rank that
+            # failed alone would leave the others waiting in the communicator's rendezvous for ever)
+            import torch
+            import torch.distributed as dist
+            try:
+                b.slab_unique_id()
+                can = 1
+            except K.PiclesError as e:
+                can = 0
+                print(f"[picles_amd] rank {rank}: RCCL cannot be bound ({e})", file=sys.stderr, flush=True)
+            flag = torch.tensor([can], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0:
+                if rank == 0:
+                    print("[picles_amd] native slab ring unavailable on some rank; using the torch.distributed exchange", file=sys.stderr, flush=True)
+                return
         try:
             uid = b.slab_unique_id() if rank == 0 else None
             if world > 1:

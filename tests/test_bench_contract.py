@@ -28,13 +28,30 @@ def _check(d, need_cpu):
         assert c["value"] > 0 and c["cores"] >= 1
 
 
-def test_committed_profile_line():
-    lines = [l for l in (ROOT / "profiles" / "r1_bench.json").read_text().splitlines() if l.startswith("{")]
+@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json"])
+def test_committed_profile_line(name):
+    lines = [l for l in (ROOT / "profiles" / name).read_text().splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     _check(d, need_cpu=True)
     assert d["config"]["grid"] == [4096, 4096] and d["n_gpus"] == 1
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 64 * d["config"]["particles"]
+    if name.startswith("r2"):
+        _check_round2_fields(d)
+
+
+def _check_round2_fields(d):
+    """round 2: the honest spread rides in the same line, the kernel time is reported as min / median / mean, the timed
+    region is one native call and the result is checked after it"""
+    r = d["roofline"]
+    assert r["min_launch_ms"] <= r["median_launch_ms"] <= 1.2 * r["avg_launch_ms"] and r["launches"] == d["steps"]
+    assert d["config"]["step_loop"].startswith("native") and d["config"]["host_enqueue_us_per_step"] < 100
+    assert d["state_check"]["rel_spread"] < 1e-9
+    sec = {(tuple(s["winds"]), s["solver"]): s for s in d["secondary"]}
+    assert set(sec) == {((10.0, 3.0), "DP5"), ((10.0, 3.0), "AutoTsit5"), ((10.0, 10.0), "AutoTsit5")}
+    for s in sec.values():
+        assert s["ms_per_step"] > 0 and s["rhs_evals_per_particle_step"] > 20 and 0 < s["fp64_frac"] < 1 and s["halo_overflow"] == 0
+    assert sec[((10.0, 3.0), "DP5")]["rhs_evals_per_particle_step"] > 5 * d["fp64"]["rhs_evals_per_particle_step"]
 
 
 @pytest.mark.gpu
@@ -46,13 +63,15 @@ def test_live_bench_prints_one_json_line():
     d = json.loads(lines[0])
     _check(d, need_cpu=True)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["config"]["particles"] == 256 * 256
+    _check_round2_fields(d)
 
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_ring_of_one_bench_prints_one_json_line():
-    """the N > 1 flow of bench.py (RCCL process group, barrier + all-reduce of the timings, per-step halo exchange) on a
-    one-rank group: stdout still carries exactly one JSON line although RCCL prints its banner"""
+    """the N > 1 data path of bench.py (native slab ring: the library's own RCCL communicator, edge / interior streams, halo
+    blocks sent to ourselves and consumed by the pull) on one rank: stdout still carries exactly one JSON line although RCCL
+    prints its banner"""
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--ring-of-one", "--steps", "4", "--warmup", "1",
                           "--grid-n", "256", "--no-cpu"], check=True, capture_output=True, text=True).stdout
     lines = [l for l in out.splitlines() if l.strip()]
@@ -60,3 +79,5 @@ def test_ring_of_one_bench_prints_one_json_line():
     d = json.loads(lines[0])
     _check(d, need_cpu=False)
     assert d["n_gpus"] == 1 and d["steps"] == 4
+    assert "picles_slab_run_steps" in d["config"]["step_loop"] and d["roofline"]["launches"] == 8      # edge + interior per step
+    assert d["state_check"]["rel_spread"] < 1e-9
