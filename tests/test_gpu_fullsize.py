@@ -56,7 +56,7 @@ def _step(m, cfg, observe=True):
         movie_time_step(m, cfg.Δt)
         return m.MovieState
     time_step(m, cfg.Δt, zero_first=True)
-    return m.State if observe else None
+    return m.State.copy() if observe else None      # a copy: model.State is a lazy VIEW of the device field, it follows later steps
 
 
 def _same_particles(mg, mo):
