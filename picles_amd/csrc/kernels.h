@@ -1,0 +1,565 @@
+/*
+ * kernels.h — device-side code shared by the translation units of libpicles_hip.so: the kernel argument structs (GridP, Arrays),
+ * the per-particle step (advance_particle, write_record, flush_stats), NodeToParticle! in registers and the deterministic pull
+ * scatter.  Everything here is __device__ __forceinline__ or a plain struct; the kernels themselves live in
+ *   picles_hip.hip      k_seed, k_scatter, k_remesh, k_push_tiles, the cell list, k_wind_sample + the host side / C ABI
+ *   k_step_explicit.hip  the fused step, DP5 and Tsit5 flavours          k_step_auto.hip   ... AutoTsit5(Rosenbrock23())
+ *   k_advance.hip        the stand-alone advance
+ * (split so that the flavours compile in parallel: `make -j`).
+ */
+#ifndef PICLES_KERNELS_H
+#define PICLES_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/picles_hip.h"
+#include "physics.h"
+
+/* ------------------------------------------------------------------------------------------ */
+struct GridP {
+    int Nx, Ny;            /* global */
+    int periodic_x, periodic_y;
+    int tripolar;          /* N_TripolarNorth: y is not periodic; corners beyond the north edge fold back, mirrored in x */
+    int j_begin, ny_loc;
+    int R;                 /* ghost record rows per side (halo blocks); row offset of the records */
+    int Rp;                /* reach of the pull scatter: >0 fixed (slabs: = R), 0 = read the
+                              max_reach the advance kernel measured (single slab, no host sync) */
+    int single_slab;       /* this context owns all rows: wrap in y is local */
+    int ngroups;           /* 1, or 2 when grid-boundary (mask 3) particles are stepped */
+};
+
+/* Statistics are accumulated in NSLOTS independent slots (one 64-B line each) chosen by wave:
+ * a single shared counter line serialises the 2.4 M per-launch wave atomics in one L2 channel
+ * (measured: +9 ms per 4096² launch); spread over 1024 lines they are free. */
+#define NSLOTS 1024
+struct DevCounters {
+    unsigned long long rhs, acc, rej, reseeds, clamps, maxit, adv, overflow;
+    unsigned long long nonfinite, pad_[7];     /* two 64-B lines per slot */
+};
+
+struct Arrays {
+    double *state, *movie;   /* 3 planes */
+    double *z;               /* 5 planes */
+    double *qold, *dtn;
+    int *asw;                /* solver 2: AutoSwitch state (counter << 1 | rosenbrock_active; ASW_FRESH after a reinit!) */
+    unsigned char *on, *pflags;
+    int *status;
+    double *u0, *v0, *u1, *v1;
+    double *uP, *vP;         /* level-0 winds of the previous step's window (fused steps under time-varying winds) */
+    double *m11, *m22, *pc;  /* per-node projection diag and great-circle coefficient (NULL: Cartesian) */
+    double *rec;             /* records the scatter reads  (latest completed advance) */
+    double *rec_out;         /* records the advance writes (the other buffer of the pair) */
+    DevCounters *cnt;        /* [NSLOTS] */
+    int *max_reach;          /* max scatter reach of the records in `rec` (read by the pull) */
+    int *max_reach_out;      /* ... of the records being written to `rec_out` */
+    int *max_reach_total;    /* running maximum since the last reset (slab halos are sized from it) */
+    int *max_reach_next;     /* the counter the NEXT step will write: cleared by this step's advance launches (three counters
+                                rotate — read / written / cleared — so no per-step memset launch sits between the steps) */
+    long long n;             /* Nx * ny_loc */
+};
+
+#define PF_STEPPED 1
+#define PF_GROUP2 2
+#define PF_BOUNDARY 4
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, 64);
+        v = (t > v) ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, long long t)
+{
+    Wind w;
+    w.u0 = A.u0[t];
+    w.v0 = A.v0[t];
+    if (P.wind_static) {
+        w.du = 0.0;
+        w.dv = 0.0;
+    } else {
+        w.du = A.u1[t] - w.u0;
+        w.dv = A.v1[t] - w.v0;
+    }
+    return w;
+}
+
+__device__ __forceinline__ double *rec_row(const Arrays &A, const GridP &G, int row)
+{
+    return A.rec + (size_t)row * 6 * G.Nx;
+}
+__device__ __forceinline__ double *rec_row_out(const Arrays &A, const GridP &G, int row)
+{
+    return A.rec_out + (size_t)row * 6 * G.Nx;
+}
+
+/* scatter record plane 5: 0.0 = no contribution, else list (1 ocean, 2 grid boundary) and the
+ * cell offsets (bx, by) = floor(x), floor(y) of the particle, packed into an exactly
+ * representable integer-valued double (the planes stay one dtype => contiguous halo blocks) */
+#define REC_BIAS 2048
+/* A whole-grid context follows the scatter reach the advance measured, up to this many cells per model step; a
+ * particle that travels farther (not a sea state: 64 cells are > 100 km in 10 minutes on the reference's meshes) is
+ * not scattered and is counted in `halo_overflow`.  The pull visits (2R+1)² candidates per node: the cap also bounds
+ * the cost of a step poisoned by one runaway particle. */
+#define REACH_CAP 64
+__device__ __forceinline__ double rec_encode(int grp, int bx, int by)
+{
+    return (double)(grp + 4 * (bx + REC_BIAS) + 4 * 4096 * (by + REC_BIAS));
+}
+__device__ __forceinline__ void rec_decode(double code, int &grp, int &bx, int &by)
+{
+    int ci = (int)code;
+    grp = ci & 3;
+    bx = ((ci >> 2) & 4095) - REC_BIAS;
+    by = (ci >> 14) - REC_BIAS;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * advance! (mapping_2D.jl:118-243) of one particle held in registers: integrate / off->on test,
+ * NaN / Inf / cap guards.  Shared by k_advance and the fused k_step.
+ * ---------------------------------------------------------------------------------------- */
+struct StepStats {
+    PStats st;
+    unsigned int adv, reseeds, clamps, maxit, overflow, nonfinite;
+    int reach;
+};
+
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
+__device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
+                                                double &dtn, double t_start, double DT, StepStats &S,
+                                                double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
+{
+    int status = PICLES_ST_STEPPED;
+    if (on) {
+        S.adv = 1;
+        integrate_dp5<FAST, STATIC, METRIC, TSIT, AUTO>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc, asw);
+        status |= S.st.status;
+    } else {
+        double u, v;
+        wind_at(P, w, t_start + DT, u, v);
+        if (u * u + v * v >= P.wind_min_sq) {
+            reseed(P, u, v, DT, z);
+            dtn = -1.0;
+            on = 1;
+            status |= PICLES_ST_SWITCHED_ON;
+        }
+    }
+    if (pm_isnan(z.lne) || pm_isnan(z.cx) || pm_isnan(z.cy)) {
+        double u, v;
+        wind_at(P, w, t_start + DT, u, v);
+        reseed(P, u, v, DT, z);
+        dtn = -1.0;
+        status |= PICLES_ST_RESEED_NAN;
+    } else if (pm_isinf(z.lne) || pm_isinf(z.cx) || pm_isinf(z.cy)) {
+        double u, v;
+        wind_at(P, w, t_start, u, v);
+        reseed(P, u, v, DT, z);
+        dtn = -1.0;
+        status |= PICLES_ST_RESEED_INF;
+    } else if (z.lne > P.lne_max) {
+        z.lne = P.lne_max;
+        dtn = -1.0;
+        status |= PICLES_ST_CLAMPED;
+    }
+    if (status & (PICLES_ST_RESEED_NAN | PICLES_ST_RESEED_INF | PICLES_ST_SWITCHED_ON)) S.reseeds = 1;
+    if (status & PICLES_ST_CLAMPED) S.clamps = 1;
+    if (status & PICLES_ST_MAXITERS) S.maxit = 1;
+    return status;
+}
+
+/* scatter record of one advanced particle (ParticleToNode! inputs): charge, upper-node weights and
+ * the packed (list, cell offset) code, into the OUT buffer */
+__device__ __forceinline__ void write_record(const GridP &G, const Arrays &A, int i, int jl, unsigned char pf, int on,
+                                             const Vec5 &z, StepStats &S)
+{
+    double *rr = rec_row_out(A, G, jl + G.R);
+    double code = 0.0;
+    if (on && !(pm_isfinite(z.x) && pm_isfinite(z.y))) {
+        S.nonfinite = 1;         /* the reference would throw in Int(floor(NaN)) (ParticleInCell.jl:58-71): dropped and counted */
+    } else if (on && !(pm_fabs(z.x) < 2047.0 && pm_fabs(z.y) < 2047.0)) {
+        S.overflow = 1;          /* farther than the record code can hold (and than any int conversion should see) */
+    } else if (on) {
+        double e, mx, my;
+        particle_to_charge(z.lne, z.cx, z.cy, e, mx, my);
+        int bx, by;
+        double wx, wy;
+        index_weight(z.x, bx, wx);
+        index_weight(z.y, by, wy);
+        int r = (bx < 0) ? -bx : bx + 1;
+        int ry = (by < 0) ? -by : by + 1;
+        S.reach = (r > ry) ? r : ry;
+        if (S.reach <= ((G.Rp > 0) ? G.Rp : REACH_CAP)) {
+            rr[i] = e; rr[G.Nx + i] = mx; rr[2 * G.Nx + i] = my; rr[3 * G.Nx + i] = wx; rr[4 * G.Nx + i] = wy;
+            code = rec_encode((pf & PF_GROUP2) ? 2 : 1, bx, by);
+        }
+        else { S.overflow = 1; S.reach = 0; }     /* not scattered, not part of the reach the pull follows */
+    }
+    rr[5 * G.Nx + i] = code;
+}
+
+/* statistics: one atomic per wave into the wave's slot.  The 0/1 flags are counted with a ballot +
+ * scalar popcount (no cross-lane traffic), the step counters with two 64-bit butterfly sums
+ * (accepted and rejected steps share one word), the reach with a ballot ladder. */
+__device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
+{
+    unsigned long long s_rhs = wave_sum_u64(S.st.rhs);
+    unsigned long long s_ar = wave_sum_u64(((unsigned long long)S.st.acc << 32) | S.st.rej);
+    unsigned long long b_adv = __ballot(S.adv != 0), b_res1 = __ballot(S.reseeds == 1), b_res2 = __ballot(S.reseeds >= 2);
+    unsigned long long b_cl = __ballot(S.clamps != 0), b_mx = __ballot(S.maxit != 0), b_ov = __ballot(S.overflow != 0);
+    unsigned long long b_nf = __ballot(S.nonfinite != 0);
+    int m_reach = 0;
+    if (__ballot(S.reach > 0)) {
+        m_reach = 1;
+        while (__ballot(S.reach > m_reach)) m_reach++;   /* reach is 1 in all but exotic steps: one extra ballot */
+    }
+    if ((threadIdx.x & 63) == 0) {
+        DevCounters *c = A.cnt + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (NSLOTS - 1));
+        unsigned long long s_acc = s_ar >> 32, s_rej = s_ar & 0xffffffffULL;
+        unsigned long long s_res = (unsigned long long)__popcll(b_res1) + 2ull * __popcll(b_res2);
+        if (s_rhs) atomicAdd(&c->rhs, s_rhs);
+        if (s_acc) atomicAdd(&c->acc, s_acc);
+        if (s_rej) atomicAdd(&c->rej, s_rej);
+        if (b_adv) atomicAdd(&c->adv, (unsigned long long)__popcll(b_adv));
+        if (s_res) atomicAdd(&c->reseeds, s_res);
+        if (b_cl) atomicAdd(&c->clamps, (unsigned long long)__popcll(b_cl));
+        if (b_mx) atomicAdd(&c->maxit, (unsigned long long)__popcll(b_mx));
+        if (b_ov) atomicAdd(&c->overflow, (unsigned long long)__popcll(b_ov));
+        if (b_nf) atomicAdd(&c->nonfinite, (unsigned long long)__popcll(b_nf));
+        /* one address for the whole grid: only waves that would raise it touch it */
+        if (m_reach > __hip_atomic_load(A.max_reach_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(A.max_reach_out, m_reach);
+        if (m_reach > __hip_atomic_load(A.max_reach_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(A.max_reach_total, m_reach);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *A.max_reach_next = 0;     /* nobody reads or writes it during this step */
+    }
+}
+
+/* XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8),
+ * each with its own L2.  The pull scatter of a node reads the records of the rows above and below,
+ * so vertically adjacent 256-node segments should share an L2: give every XCD one contiguous band
+ * of the index space (logical block = (b % 8) * ceil(n/8) + b / 8).  Placement is a speed matter only. */
+__device__ __forceinline__ unsigned int xcd_block(void)
+{
+    const unsigned int n = gridDim.x, b = blockIdx.x;
+    const unsigned int per = (n + 7u) / 8u;
+    unsigned int l = (b % 8u) * per + b / 8u;
+    /* grids that are not a multiple of 8: the tail of the last bands is empty; fall back to identity there */
+    return (n % 8u == 0u) ? l : b;
+}
+
+/* local rows [r0, r0+n0) ∪ [r1, r1+n1) -> particle index */
+__device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r1, int n1, long long &t)
+{
+    long long tid = (long long)xcd_block() * blockDim.x + threadIdx.x;
+    long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
+    if (tid >= na + nb) return false;
+    t = (tid < na) ? (long long)r0 * G.Nx + tid : (long long)r1 * G.Nx + (tid - na);
+    return true;
+}
+
+/* NodeToParticle! (mapping_2D.jl:279-356) on the node value (e,mx,my), all in registers.
+ * Returns the branch: 0 = A (node -> particle), 1 = B/C (re-seed from the wind), 2 = D (off). */
+__device__ __forceinline__ int remesh_regs(const KParams &P, const Wind &w, unsigned char pf, double e, double mx,
+                                           double my, double clock, double DT, Vec5 &z)
+{
+    double u, v;
+    wind_at(P, w, clock, u, v);          /* winds at model.clock.time, before tick! */
+    bool bnd = (pf & PF_BOUNDARY) != 0;
+    if (!bnd && (e >= P.min_e) && (mx * mx + my * my >= P.min_m2)) {
+        charge_to_particle(e, mx, my, z);
+        return 0;
+    }
+    if (u * u + v * v >= P.wind_min_sq) {
+        reseed(P, u, v, DT, z);
+        return 1;
+    }
+    return 2;
+}
+
+/* the same decision with the node wind behind pointers: it is read only by the (rare) branches that need it */
+__device__ __forceinline__ int remesh_regs_lazy(const KParams &P, unsigned char pf, double e, double mx, double my,
+                                                double DT, Vec5 &z, const double *pu, const double *pv)
+{
+    bool bnd = (pf & PF_BOUNDARY) != 0;
+    if (!bnd && (e >= P.min_e) && (mx * mx + my * my >= P.min_m2)) {
+        charge_to_particle(e, mx, my, z);
+        return 0;
+    }
+    double u = *pu, v = *pv;
+    if (u * u + v * v >= P.wind_min_sq) {
+        reseed(P, u, v, DT, z);
+        return 1;
+    }
+    return 2;
+}
+
+__device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &A, long long t, unsigned char pf,
+                                                double e, double mx, double my, double clock, double DT,
+                                                unsigned int &reseeds)
+{
+    Wind w = load_wind(P, A, t);
+    Vec5 z;
+    int br = remesh_regs(P, w, pf, e, mx, my, clock, DT, z);
+    if (br <= 1) {
+        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = 0.0; A.z[t + 4 * A.n] = 0.0;
+        if (br == 1) { A.qold[t] = PI_LNQOLDINIT; A.asw[t] = ASW_FRESH; reseeds = 1; }   /* reinit! */
+        A.dtn[t] = -1.0;
+        A.on[t] = 1;
+    } else {
+        A.on[t] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_scatter — ParticleToNode! / push_to_grid! (mapping_2D.jl:59-73, ParticleInCell.jl:341-376,
+ * 504-508,530-538) as a deterministic PULL: node (i,j) visits its (2R+1)² candidate source
+ * particles in the reference's sequential order (ocean list then grid-boundary list, each
+ * column-major; periodic wraps sorted by their wrapped index) and adds (wx*wy)*charge of the
+ * one corner that lands on it.  Drop/wrap per axis follows the GRID's periodicity.
+ * Fused: State zero-fill (accum=0), MovieState snapshot + post-remesh zero (movie=1),
+ * remesh (REMESH).
+ * ---------------------------------------------------------------------------------------- */
+/* one candidate source: record element offset `off` (plane 0 of the source particle), cell offsets
+ * (di, dj) of the source relative to the node */
+__device__ __forceinline__ void pull_candidate(const double *__restrict__ rec, unsigned int off, unsigned int pl, int di, int dj,
+                                               int grp, bool ok, double &s0, double &s1, double &s2)
+{
+    /* the source feeds this node iff its group matches and its cell offset is (-di - ax, -dj - ay) with
+     * ax, ay in {0, 1}: in code space that is code - code(grp, -di - 1, -dj - 1) in {0, 4, 16384, 16388}
+     * (bit 2 clear = upper x node, bit 14 clear = upper y node); an empty record (code 0) gives a negative
+     * difference */
+    const int d = (int)rec[off + 5u * pl] - (grp + 4 * (REC_BIAS - 1 - di) + 4 * 4096 * (REC_BIAS - 1 - dj));
+    if (ok && (d & ~(4 | 16384)) == 0) {
+        const bool ax = !(d & 4), ay = !(d & 16384);
+        double wxh = rec[off + 3u * pl], wyh = rec[off + 4u * pl];
+        double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
+        s0 += w * rec[off];
+        s1 += w * rec[off + pl];
+        s2 += w * rec[off + 2u * pl];
+    }
+}
+
+/* floor(a / b) for b > 0 */
+__device__ __forceinline__ int floor_div(int a, int b) { int q = a / b; return (a % b < 0) ? q - 1 : q; }
+
+/* General form of the pull for a reach that wraps around a periodic axis (2R + 1 > N: tiny grids, huge
+ * steps): several offsets d alias the same source row / column.  Sources are visited in ascending
+ * wrapped index (the reference's sequential order); for each one every aliasing offset is tried (at most
+ * one can match, the cell offset stored in the record decides).  O(N) per axis, only used when needed. */
+__device__ __forceinline__ void pull_node_aliased(const GridP &G, const Arrays &A, int i, int jl, int R,
+                                  double &s0, double &s1, double &s2)
+{
+    const int RO = G.R, Nx = G.Nx, Ny = G.Ny, j = jl + G.j_begin;
+    const double *__restrict__ rec = A.rec;
+    const unsigned int pl = (unsigned int)Nx, rowlen = 6u * pl;
+    const int jlo = G.periodic_y ? 0 : max(0, j - R), jhi = G.periodic_y ? Ny - 1 : min(Ny - 1, j + R);
+    const int ilo = G.periodic_x ? 0 : max(0, i - R), ihi = G.periodic_x ? Nx - 1 : min(Nx - 1, i + R);
+    const bool wrap_y = G.periodic_y && G.single_slab;     /* slabs: a periodic y never aliases (checked at create) */
+    for (int grp = 1; grp <= G.ngroups; grp++) {
+        for (int js = jlo; js <= jhi; js++) {
+            int dj0 = js - j;
+            if (G.periodic_y) dj0 -= floor_div(dj0 + R, Ny) * Ny;          /* smallest alias >= -R */
+            if (dj0 > R) continue;
+            for (int is = ilo; is <= ihi; is++) {                          /* sources in ascending index ... */
+                int di0 = is - i;
+                if (G.periodic_x) di0 -= floor_div(di0 + R, Nx) * Nx;
+                /* ... each with all its aliasing offsets (at most one pair can match a corner of this source) */
+                for (int dj = dj0; dj <= R; dj += (G.periodic_y ? Ny : 2 * R + 1)) {
+                    const int row = (wrap_y || !G.periodic_y ? js - G.j_begin : jl + dj) + RO;
+                    for (int di = di0; di <= R; di += (G.periodic_x ? Nx : 2 * R + 1))
+                        pull_candidate(rec, (unsigned int)row * rowlen + (unsigned int)is, pl, di, dj, grp, true, s0, s1, s2);
+                }
+            }
+        }
+    }
+}
+
+/* sum of the contributions to node (i, j); RT > 0: reach known at compile time (fully unrolled:
+ * all candidate codes are loaded before any is inspected), RT == 0: runtime reach R.
+ * Record elements are addressed with 32-bit offsets from one base pointer (the host falls back to
+ * a single-plane-per-call layout check: (ny_loc + 2R) * 6 * Nx < 2^31 elements). */
+template <int RT>
+__device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i, int jl, int Rdyn,
+                                          double &s0, double &s1, double &s2)
+{
+    const int R = RT ? RT : Rdyn, W = 2 * R + 1;
+    const int RO = G.R;   /* row offset of the own rows inside rec */
+    const int j = jl + G.j_begin, Nx = G.Nx;
+    const double *__restrict__ rec = A.rec;
+    const unsigned int pl = (unsigned int)Nx, rowlen = 6u * pl;
+    /* interior nodes: no wrap, no drop, natural (= reference) order */
+    bool interior = (i - R >= 0) && (i + R < Nx) && (j - R >= 0) && (j + R < G.Ny);
+    if (interior) {
+        const unsigned int base = (unsigned int)(jl + RO) * rowlen + (unsigned int)i;
+        for (int grp = 1; grp <= G.ngroups; grp++) {
+            if constexpr (RT == 1) {
+#pragma unroll
+                for (int dj = -1; dj <= 1; dj++) {
+#pragma unroll
+                    for (int di = -1; di <= 1; di++)
+                        pull_candidate(rec, base + (unsigned int)(dj * (int)rowlen + di), pl, di, dj, grp, true, s0, s1, s2);
+                }
+            } else {
+                /* wider reach: one row of candidates at a time keeps the register footprint of the
+                 * fused step kernel at two waves per SIMD */
+#pragma unroll 1
+                for (int dj = -R; dj <= R; dj++) {
+                    const unsigned int rb = base + (unsigned int)(dj * (int)rowlen);
+                    if constexpr (RT != 0) {
+#pragma unroll
+                        for (int di = -RT; di <= RT; di++)
+                            pull_candidate(rec, rb + (unsigned int)di, pl, di, dj, grp, true, s0, s1, s2);
+                    } else {
+                        for (int di = -R; di <= R; di++)
+                            pull_candidate(rec, rb + (unsigned int)di, pl, di, dj, grp, true, s0, s1, s2);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    int shx = 0, shy = 0;
+    if (G.periodic_x) { if (i - R < 0) shx = R - i; else if (i + R >= Nx) shx = Nx - i + R; }
+    if (G.periodic_y) { if (j - R < 0) shy = R - j; else if (j + R >= G.Ny) shy = G.Ny - j + R; }
+    for (int grp = 1; grp <= G.ngroups; grp++) {
+#pragma unroll 1
+        for (int sj = 0; sj < W; sj++) {
+            int qj = sj + shy; if (qj >= W) qj -= W;
+            int dj = qj - R;
+            int jj = j + dj;
+            bool rowok = G.periodic_y || (jj >= 0 && jj < G.Ny);
+            int row;
+            if (G.single_slab) {
+                int jw = jj; if (jw < 0) jw += G.Ny; else if (jw >= G.Ny) jw -= G.Ny;
+                row = jw + RO;
+            } else {
+                row = jl + dj + RO;
+            }
+            if (!rowok) continue;   /* beyond a non-periodic edge: dropped, and nothing is read */
+#pragma unroll 1
+            for (int si = 0; si < W; si++) {
+                int qi = si + shx; if (qi >= W) qi -= W;
+                int di = qi - R;
+                int ii = i + di;
+                if (ii < 0 || ii >= Nx) {
+                    /* beyond a non-periodic edge (at ANY distance: the reach may exceed the grid): dropped, nothing
+                     * is read.  Periodic: one wrap suffices, a reach of N/2 or more takes pull_node_aliased. */
+                    if (!G.periodic_x) continue;
+                    ii += (ii < 0) ? Nx : -Nx;
+                }
+                pull_candidate(rec, (unsigned int)row * rowlen + (unsigned int)ii, pl, di, dj, grp, true, s0, s1, s2);
+            }
+        }
+    }
+}
+
+/* floor modulo for b > 0 */
+__device__ __forceinline__ int floor_mod(int a, int b) { int r = a % b; return (r < 0) ? r + b : r; }
+
+/* N_TripolarNorth (ParticleInCell.jl:353-361, TripolarNorthBoundary :409-428): a node of the top band (j >= Ny - R)
+ * receives ordinary corners and corners folded back over the north seam, mirrored in x.  Candidate sources — rows
+ * j-R .. Ny-1, columns within R of i or of the mirror column Nx-2-i — are visited in ascending index; each replays
+ * its four corners in construct_loop order through the boundary rule of the push (0-based): corner (ci, cj) with
+ * cj >= Ny lands on (Nx-1 - mod(ci+1, Nx), 2Ny-1-cj), with cj < 0 is dropped, otherwise on (mod(ci, Nx), cj). */
+__device__ __forceinline__ void pull_node_tripolar(const GridP &G, const Arrays &A, int i, int jl, int R,
+                                                   double &s0, double &s1, double &s2)
+{
+    const int RO = G.R, Nx = G.Nx, Ny = G.Ny, j = jl + G.j_begin, W = 2 * R + 1;
+    const double *__restrict__ rec = A.rec;
+    const unsigned int pl = (unsigned int)Nx, rowlen = 6u * pl;
+    const int cB = floor_mod(Nx - 2 - i, Nx);
+    const bool narrow = (2 * W <= Nx);       /* two disjoint-or-touching windows; otherwise scan the whole row */
+    const int a0 = floor_mod(i - R, Nx), b0 = floor_mod(cB - R, Nx);
+    for (int grp = 1; grp <= G.ngroups; grp++) {
+        for (int js = max(0, j - R); js < Ny; js++) {
+            const unsigned int rbase = (unsigned int)(js - G.j_begin + RO) * rowlen;
+            /* ascending merge of the two wrapped windows [a0, a0+W) and [b0, b0+W) (mod Nx) */
+            int ka = 0, kb = 0, is_full = 0;
+            while (narrow ? (ka < W || kb < W) : (is_full < Nx)) {
+                int is;
+                if (narrow) {
+                    /* element k of a wrapped window in ascending order: the wrapped-around part comes first */
+                    const int wa = a0 + W - Nx, wb = b0 + W - Nx;      /* > 0: that many elements wrap to 0.. */
+                    int ea = (ka < W) ? ((wa > 0) ? ((ka < wa) ? ka : a0 + (ka - wa)) : a0 + ka) : 0x7fffffff;
+                    int eb = (kb < W) ? ((wb > 0) ? ((kb < wb) ? kb : b0 + (kb - wb)) : b0 + kb) : 0x7fffffff;
+                    is = min(ea, eb);
+                    if (ea == is) ka++;
+                    if (eb == is) kb++;
+                } else {
+                    is = is_full++;
+                }
+                const int ci0 = (int)rec[rbase + 5u * pl + (unsigned int)is];
+                if (ci0 == 0 || (ci0 & 3) != grp) continue;
+                const int bx = ((ci0 >> 2) & 4095) - REC_BIAS, by = (ci0 >> 14) - REC_BIAS;
+                const double wxh = rec[rbase + 3u * pl + (unsigned int)is], wyh = rec[rbase + 4u * pl + (unsigned int)is];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int ax = k & 1, ay = k >> 1;
+                    int ci = is + bx + ax, cj = js + by + ay;
+                    if (cj < 0) continue;
+                    if (cj >= Ny) { ci = Nx - 1 - floor_mod(ci + 1, Nx); cj = 2 * Ny - 1 - cj; }
+                    else ci = floor_mod(ci, Nx);
+                    if (ci != i || cj != j) continue;
+                    const double w = (ax ? wxh : 1.0 - wxh) * (ay ? wyh : 1.0 - wyh);
+                    s0 += w * rec[rbase + (unsigned int)is];
+                    s1 += w * rec[rbase + pl + (unsigned int)is];
+                    s2 += w * rec[rbase + 2u * pl + (unsigned int)is];
+                }
+            }
+        }
+    }
+}
+
+/* reach dispatch: compile-time reach 1 and 2, runtime reach otherwise; a reach that wraps around a periodic
+ * axis takes the general (aliasing-aware) form */
+__device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i, int jl, int R,
+                                         double &s0, double &s1, double &s2)
+{
+    const int W = 2 * R + 1;
+    if (G.tripolar && jl + G.j_begin >= G.Ny - R) pull_node_tripolar(G, A, i, jl, R, s0, s1, s2);
+    else if ((G.periodic_x && W > G.Nx) || (G.periodic_y && W > G.Ny)) pull_node_aliased(G, A, i, jl, R, s0, s1, s2);
+    else if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
+    else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
+    else if (R == 3) pull_node<3>(G, A, i, jl, 3, s0, s1, s2);     /* a fully developed sea under strong winds */
+    else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
+}
+
+/* reach the pull of local row jl must cover.  A whole-grid context follows the reach its own advance measured.  A slab
+ * covers halo_rows for the rows that can receive from a neighbour's particles (the edge rows: the neighbour's reach is not
+ * known here), and for its interior rows — fed by own particles only — again the measured reach, which is what keeps the
+ * common case at 9 candidates per node instead of (2 halo_rows + 1)².  Any reach >= the true one gives the same bits. */
+__device__ __forceinline__ int pull_reach(const GridP &G, const Arrays &A, int jl)
+{
+    if (G.Rp > 0 && (jl < G.R || jl >= G.ny_loc - G.R)) return G.Rp;
+    int m = *A.max_reach;
+    if (m < 1) m = 1;
+    return (G.Rp > 0 && m > G.Rp) ? G.Rp : m;
+}
+
+
+/* launchers of the kernel families that live in their own translation units (k_step_*.hip, k_advance.hip) */
+struct StepLaunch {
+    dim3 grid, block;
+    hipStream_t stream;
+    const KParams *P;
+    const GridP *G;
+    const Arrays *A;
+    double t_prev, DT_prev, t_start, DT;
+    int r0, n0, r1, n1;
+};
+/* fused step: fast = specialised physics; solver 0 DP5, 1 Tsit5, 2 auto-switching; wind_static; metric */
+void launch_k_step_explicit(const StepLaunch &L, bool fast, int solver, bool wind_static, bool metric);
+void launch_k_step_auto(const StepLaunch &L, bool wind_static, bool metric);
+void launch_k_advance(const StepLaunch &L, bool fast, int solver, bool wind_static, bool metric);
+
+#endif /* PICLES_KERNELS_H */
