@@ -178,10 +178,13 @@ def main():
     W, Ksteps = args.warmup, args.steps
 
     def barrier(model):
+        # device-wide synchronisation on both sides of the timed region, WITHOUT picles_sync: that call also completes ("flushes")
+        # the scatter + remesh of the last step with a stand-alone launch.  In a run of fused steps launch k does the scatter +
+        # remesh of step k-1 and the advance of step k; the region between two non-flushing barriers therefore holds exactly K
+        # launches = K scatters + K remeshes + K advances — the same work as K steps, with nothing extra and nothing skipped.
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        model.sync()
 
     def measure(winds, solver, deadband, K_, W_):
         """seed, W_ warm-up steps, then EXACTLY K_ timed steps between barriers.  The timed region is ONE call into the
@@ -194,7 +197,6 @@ def main():
                           native_ring=None if (args.backend == "nccl" and not args.python_loop) else False)
         model.seed()
         model.run_steps(cfg.Δt, W_, flags)
-        model.sync()
         model.backend.reset_counters()
         model.backend.enable_timing(not args.no_events)
         barrier(model)

@@ -194,7 +194,7 @@ int32_t picles_get_particles(picles_ctx *ctx, double *z, uint8_t *on, uint8_t *b
 int32_t picles_set_particles(picles_ctx *ctx, const double *z, const uint8_t *on);
 
 int32_t picles_get_counters(picles_ctx *ctx, picles_counters *c);   /* syncs */
-int32_t picles_reset_counters(picles_ctx *ctx);
+int32_t picles_reset_counters(picles_ctx *ctx);                    /* syncs the device; does NOT complete a pending fused step */
 int32_t picles_enable_timing(picles_ctx *ctx, int32_t on);
 int32_t picles_get_timing(picles_ctx *ctx, picles_timing *t);       /* syncs */
 /* per-launch device durations [ms] since picles_enable_timing(1): kind 0 = step / advance launches, 1 = scatter, 2 = remesh.

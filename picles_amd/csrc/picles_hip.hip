@@ -1265,7 +1265,8 @@ PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
-    { int rc = flush(c); if (rc) return rc; }
+    /* no flush: a pending fused step stays pending (its scatter + remesh ride on the next step's launch as usual; the
+     * re-seeds of that remesh are then counted in the new window — as the last step of the window leaves its own behind) */
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
     HIPCHK(c, hipMemsetAsync(c->A.max_reach_total, 0, sizeof(int), c->stream));
@@ -1275,8 +1276,7 @@ PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
 PX_EXPORT int32_t picles_enable_timing(picles_ctx *c, int32_t on)
 {
     if (!c) return -1;
-    { int rc = flush(c); if (rc) return rc; }
-    timing_collect(c);
+    timing_collect(c);          /* (does not flush a pending fused step: see picles_reset_counters) */
     c->timing = on != 0;
     if (on) { memset(&c->tim, 0, sizeof(c->tim)); for (auto &v : c->tim_samples) v.clear(); }
     return 0;
