@@ -513,9 +513,7 @@ static Arrays arrays_for(picles_ctx *c, int read_buf, int write_buf)
     A.rec_out = c->rec_buf[write_buf];
     /* reach counters rotate with the steps, independently of the record pair: a launch that scatters the records it has just
      * written (read_buf == write_buf: k_scatter after k_advance) reads the counter of the step in flight */
-    A.max_reach = c->mr_buf[read_buf == write_buf ? c->mr_w : (c->mr_w + 4) % 5];
-    A.max_reach_out = c->mr_buf[c->mr_w];
-    A.max_reach_next = c->mr_buf[(c->mr_w + 2) % 5];
+    A.mr_idx = (read_buf == write_buf ? c->mr_w : (c->mr_w + 4) % 5) | (c->mr_w << 4) | (((c->mr_w + 2) % 5) << 8);
     return A;
 }
 
@@ -670,13 +668,9 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     CK(hipMalloc(&A.qold, n * 8)); CK(hipMalloc(&A.dtn, n * 8)); CK(hipMalloc(&A.asw, n * 4)); CK(hipMemset(A.asw, 0, n * 4));
     CK(hipMalloc(&A.on, n)); CK(hipMalloc(&A.pflags, n)); CK(hipMalloc(&A.status, n * 4));
     CK(hipMalloc(&A.u0, n * 8)); CK(hipMalloc(&A.v0, n * 8)); CK(hipMalloc(&A.u1, n * 8)); CK(hipMalloc(&A.v1, n * 8));
-    CK(hipMalloc(&A.cnt, NSLOTS * sizeof(DevCounters)));
-    CK(hipMalloc(&A.max_reach_total, sizeof(int)));
-    CK(hipMemset(A.max_reach_total, 0, sizeof(int)));
-    for (int k = 0; k < 5; k++) {
-        CK(hipMalloc(&c->mr_buf[k], sizeof(int)));
-        CK(hipMemset(c->mr_buf[k], 0, sizeof(int)));
-    }
+    CK(hipMalloc(&A.cnt, NSLOTS * sizeof(DevCounters) + 16 * sizeof(int)));     /* + the reach counters (kernels.h: reach_counters) */
+    for (int k = 0; k < 5; k++) c->mr_buf[k] = (int *)(A.cnt + NSLOTS) + k;     /* five rotating reach counters; [5] = the running maximum */
+    CK(hipMemset(c->mr_buf[0], 0, 16 * sizeof(int)));
     for (int k = 0; k < 2; k++) {
         CK(hipMalloc(&c->rec_buf[k], rec_bytes(c)));
         CK(hipMemset(c->rec_buf[k], 0, rec_bytes(c)));
@@ -704,10 +698,10 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.asw); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
-    hipFree(A.cnt); hipFree(A.max_reach_total); hipFree(c->d_mask);
+    hipFree(A.cnt); hipFree(c->d_mask);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
     for (int k = 0; k < 2; k++) hipFree(c->rec_buf[k]);
-    for (int k = 0; k < 5; k++) hipFree(c->mr_buf[k]);
+
     for (auto p : c->store_dev) hipFree(p);
     for (auto p : c->store_host) hipHostFree(p);
     for (auto e : c->store_ready) hipEventDestroy(e);
@@ -864,7 +858,7 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
         if (k == 0) for (int q = 2; q < 5; q++) HIPCHK(c, hipMemsetAsync(c->mr_buf[q], 0, sizeof(int), c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->A.max_reach_total, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mr_buf[0] + 5, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, arrays_for(c, 0, 0), c->d_mask, c->od.timestep);
     HIPCHK(c, hipGetLastError());
     c->state_zero = false;
@@ -1248,7 +1242,7 @@ PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
     if (rc) return rc;
     int mr = 0, mrt = 0;
     if ((rc = d2h(c, &mr, c->mr_buf[c->mr_w], sizeof(int)))) return rc;
-    if ((rc = d2h(c, &mrt, c->A.max_reach_total, sizeof(int)))) return rc;
+    if ((rc = d2h(c, &mrt, c->mr_buf[0] + 5, sizeof(int)))) return rc;
     memset(out, 0, sizeof(*out));
     for (const DevCounters &k : d) {
         out->rhs_evals += k.rhs; out->steps_accepted += k.acc; out->steps_rejected += k.rej;
@@ -1269,7 +1263,7 @@ PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
      * re-seeds of that remesh are then counted in the new window — as the last step of the window leaves its own behind) */
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->A.max_reach_total, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mr_buf[0] + 5, 0, sizeof(int), c->stream));
     return 0;
 }
 
