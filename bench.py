@@ -228,7 +228,9 @@ def main():
     # energy plane must be one value on every node of every slab (a lost or doubled halo row, a wrong neighbour across a slab
     # seam or a stale ghost row breaks it at the seams)
     state_check = None
-    if args.winds[0] == args.winds[1] or world > 1:
+    # (not for --atomic: the atomic push sums in run-dependent order, and that last-bit noise is amplified by the stiff direction
+    # mode to the solver tolerance — DESIGN.md §3; the headline path is the deterministic pull)
+    if (args.winds[0] == args.winds[1] or world > 1) and not args.atomic:
         e = model.get_state()[..., 0]
         ext = torch.tensor([float(e.min()), -float(e.max())], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         if use_dist:
@@ -306,7 +308,8 @@ def main():
         out["state_check"] = state_check
         out["config"]["host_enqueue_us_per_step"] = 1e6 * model.host_enqueue_s / Ksteps
         out["config"]["step_loop"] = ("native: picles_slab_run_steps (RCCL send/recv issued from C)" if model.native else
-                                      ("native: picles_run_steps" if world == 1 else "python: torch.distributed P2P per step"))
+                                      ("native: picles_run_steps" if (world == 1 and not args.atomic and model.ex is None) else
+                                       "python: one C call per step" + ("" if world == 1 else ", torch.distributed P2P")))
         if world == 1 and not args.no_secondary and not args.atomic and not args.ring_of_one:
             # the honest spread: the BASELINE winds (10,10) are the best case of the explicit pair; a generic
             # wind direction and the reference's DEFAULT solver, same box, same process

@@ -389,13 +389,19 @@ class SlabModel:
         """n consecutive model steps; with the native ring and winds the device can produce by itself (static, or a
         device-resident lattice) this is ONE call into the library — no interpreter between the steps"""
         from .wind_emulator import GriddedWinds
-        hands_off = self.native and (self.static or isinstance(self.winds, GriddedWinds)) and self.auto_halo_every <= 0
-        if not hands_off:
+        device_winds = self.static or isinstance(self.winds, GriddedWinds)
+        hands_off = self.native and device_winds and self.auto_halo_every <= 0
+        whole_grid = (self.ex is None and not self.native and device_winds and flags == K.STEP_ZERO_FIRST
+                      and hasattr(self.backend, "run_steps"))
+        if not (hands_off or whole_grid):
             for _ in range(n):
                 self.time_step(dt, flags)
             return
         self.upload_winds(self.clock, dt)
-        self.backend.slab_run_steps(dt, n, flags)
+        if whole_grid:
+            self.backend.run_steps(dt, n)           # picles_run_steps: one context, the loop of run! in C
+        else:
+            self.backend.slab_run_steps(dt, n, flags)
         self.clock += n * dt
         self._steps_done += n
 
