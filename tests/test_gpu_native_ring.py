@@ -129,3 +129,49 @@ def test_python_driven_ring_matches_native_ring():
     for _ in range(6):
         time_step(plain, cfg.Δt, zero_first=True)
     assert_bitwise(S, plain.State, "State")
+
+
+N_RING_SEEDS = int(__import__("os").environ.get("PICLES_RING_FUZZ_SEEDS", "40"))
+
+
+@pytest.mark.parametrize("seed", range(N_RING_SEEDS))
+def test_native_ring_random_scenarios_bitwise(seed):
+    """the scenarios of tests/test_gpu_fuzz.py (masks, per-axis periodicity in x, calm bands, time-varying host winds, all three
+    solvers, physics switches, run!/movie stepping) made periodic in y and run as a native ring of one in slab mode — every
+    step's ghost rows travel through RCCL — against the plain context, bitwise.  Time-varying host winds take the un-fused
+    phases (k_advance on two streams, exchange, k_scatter), static winds the fused ones."""
+    from test_gpu_fuzz import scenario
+    from picles_amd.grids import TwoDCartesianGridMesh
+    from picles_amd.models import WaveGrowth2D
+
+    def build():
+        cfg = scenario(seed)
+        g = cfg.model["grid"]
+        st = g.stats
+        ocean = (g.data.mask == 1) | (g.data.mask == 3)
+        per_x = type(st.Nx).__name__ == "N_Periodic"
+        cfg.model["grid"] = TwoDCartesianGridMesh(st.xmin, st.xmax, int(st.Nx), st.ymin, st.ymax, int(st.Ny), mask=ocean,
+                                                  periodic_boundary=(per_x, True))
+        return cfg
+    cfg = build()
+    halo = 2
+    if int(cfg.model["grid"].stats.Ny) <= 2 * halo:
+        pytest.skip("mesh too short for two ghost rows per side")
+    ring = SlabModel(cfg.model, 0, 1, device=0, halo_rows=halo, ring_of_one=True)
+    assert ring.native
+    ring.seed()
+    plain = WaveGrowth2D(**build().model)
+    initialize_simulation(Simulation(plain, Δt=cfg.Δt, stop_time=1.0))
+    flags = K.STEP_ZERO_FIRST if cfg.mode == "run" else K.STEP_MOVIE
+    for k in range(cfg.n_steps):
+        ring.time_step(cfg.Δt, flags)
+        plain.upload_winds(plain.clock.time, cfg.Δt)
+        plain.backend.time_step(cfg.Δt, flags)
+        plain.clock.time += cfg.Δt
+        cr, cp = ring.backend.get_counters(), plain.backend.get_counters()
+        if cr["halo_overflow"] or cp["halo_overflow"] or cp["max_reach_seen"] > halo:
+            return          # a particle out-ran two ghost rows (counted, not scattered): beyond what this ring covers
+        a = ring.get_state() if cfg.mode == "run" else ring.backend.get_movie_state()
+        b = plain.backend.get_state() if cfg.mode == "run" else plain.backend.get_movie_state()
+        assert_bitwise(a, b, f"seed {seed} ({cfg.desc}) step {k}")
+    _same(ring, plain)
