@@ -1442,7 +1442,6 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclCommFinalize) CommFinalize = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -1466,7 +1465,6 @@ static RcclApi *rccl_api(std::string &err)
 #define RSYM(f) do { api.f = (decltype(api.f))dlsym(h, "nccl" #f); if (!api.f) { err = "librccl lacks nccl" #f; return nullptr; } } while (0)
     RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(CommDestroy); RSYM(GroupStart); RSYM(GroupEnd); RSYM(Send); RSYM(Recv);
     RSYM(GetErrorString);
-    api.CommFinalize = (decltype(api.CommFinalize))dlsym(h, "ncclCommFinalize");     /* optional (NCCL >= 2.14) */
 #undef RSYM
     api.handle = h;
     return &api;
@@ -1511,14 +1509,7 @@ PX_EXPORT int32_t picles_slab_comm_destroy(picles_ctx *c)
     if (!R) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    if (R->comm) {
-        const char *mode = getenv("PICLES_RING_TEARDOWN");      /* destroy (default) | finalize | keep — diagnostics */
-        if (mode && !strcmp(mode, "keep")) { /* leave the communicator to process exit */ }
-        else {
-            if (mode && !strcmp(mode, "finalize") && R->api->CommFinalize) R->api->CommFinalize(R->comm);
-            R->api->CommDestroy(R->comm);
-        }
-    }
+    if (R->comm) R->api->CommDestroy(R->comm);
     if (R->evE) hipEventDestroy(R->evE);
     if (R->evM) hipEventDestroy(R->evM);
     if (R->sE) hipStreamDestroy(R->sE);
