@@ -19,7 +19,7 @@ _libs = {}
 
 
 def build():
-    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)], check=True)
+    subprocess.run(["make", "-s", "-j2", "-C", str(ORACLE_DIR)], check=True)
 
 
 def lib(kind: str = "libm") -> C.CDLL:
