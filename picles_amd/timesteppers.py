@@ -20,7 +20,22 @@ def time_step(model, Δt: float, callbacks=None, debug=False, zero_first=False):
     model.clock.time += Δt
     model.clock.iteration += 1
     if debug:
+        collect_failed(model)        # model.FailedCollection, as time_step!(…; debug=true) fills it (TimeSteppers.jl:113-120)
         model.check_counters()
+    if callable(callbacks):
+        callbacks(model)
+
+
+def collect_failed(model):
+    """the reference pushes a MarkedParticleInstance for every particle whose step! threw (mapping_2D.jl:151-170); here the
+    per-particle status bits say which particles hit maxiters, the dtmin stop, a non-finite error estimate or were re-seeded by the
+    NaN / Inf guards in the last advance"""
+    _, _, _, st = model.backend.get_particles()
+    bad = K.ST_MAXITERS | K.ST_DTMIN | K.ST_NONFINITE | K.ST_RESEED_NAN | K.ST_RESEED_INF
+    import numpy as np
+    idx = np.argwhere((st & bad) != 0)
+    model.FailedCollection = [dict(position_ij=(int(i) + 1, int(j) + 1), status=int(st[i, j]), time=model.clock.time) for i, j in idx]
+    return model.FailedCollection
 
 
 def time_step_advance(model, Δt: float, FailedCollection=None):

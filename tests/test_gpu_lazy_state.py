@@ -93,3 +93,23 @@ def test_dropped_particles_are_surfaced():
         m.check_counters()
     c = m.backend.get_counters()
     assert c["halo_overflow"] >= 1 and c["dropped_nonfinite"] >= 1
+
+
+def test_debug_mode_fills_failed_collection_and_calls_back():
+    """time_step!(model, Δt; debug=true) (TimeSteppers.jl:113-120, run.jl:84-92): particles whose last advance failed are listed
+    in model.FailedCollection (from the per-particle status bits); a callable `callbacks` is invoked after the step"""
+    cfg = configs.bench06_box(n=48)
+    cfg.model["ODEsets"].maxiters = 3                     # nobody finishes a 10-minute step in three RK attempts
+    m = make_model(cfg, "hip")
+    initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    seen = []
+    time_step(m, cfg.Δt, zero_first=True, debug=True, callbacks=lambda mdl: seen.append(mdl.clock.time))
+    assert seen == [cfg.Δt]
+    assert len(m.FailedCollection) == 48 * 48
+    f = m.FailedCollection[0]
+    assert f["status"] & K.ST_MAXITERS and f["position_ij"] == (1, 1) and f["time"] == cfg.Δt
+    cfg2 = configs.bench06_box(n=48)
+    m2 = make_model(cfg2, "hip")
+    initialize_simulation(Simulation(m2, Δt=cfg2.Δt, stop_time=1.0))
+    time_step(m2, cfg2.Δt, zero_first=True, debug=True)
+    assert m2.FailedCollection == []
