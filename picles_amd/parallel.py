@@ -417,6 +417,8 @@ class SlabModel:
         """collective: if any rank's scatter reach has reached halo_rows, every rank adds one ghost row.
         The reach of a developing sea grows by a fraction of a cell per model step, so checking every few
         steps stays ahead of it; an actual overshoot is still counted in `halo_overflow`."""
+        if self.world == 1 and not self.native and self.ex is None:
+            return self.backend.halo_rows           # a whole-grid context follows its reach by itself
         import torch
         import torch.distributed as dist
         self.sync()
