@@ -60,7 +60,7 @@ launch_ms = json.loads([l for l in open(out / f"{R}_bench.json") if l.startswith
 tot = res[dom]["hbm_read_bytes"] + res[dom]["hbm_write_bytes"]
 lines += ["", f"Reading: the fused `{dom}` (one launch per model step) keeps the fp64 VALU issue port {res[dom]['valu_busy']*100:.0f} % busy — it is",
           f"VALU-issue bound. Its HBM traffic is {tot/1e9:.2f} GB per launch = {tot/NP:.0f} B/particle against the 64 B/particle algorithmic minimum",
-          "(records 48 B in + 48 B out, State 24 B out, winds 16 B, controller memory 8+8 B, status 4 B, flags 1 B); at the ≈5 TB/s this",
+          "(records 48 B in + 48 B out, winds 16 B, controller memory 8+8 B, status 4 B, flags 1 B; round 2 removed the 24 B State store — nobody can read State while a fused step is pending, flush() writes it); at the ≈5 TB/s this",
           f"chip sustains that is ≈{tot/5e12*1e3:.2f} ms of the ≈{launch_ms:.2f} ms launch. Before fusion (k_advance + k_scatter) the step moved 5.5 GB."]
 ring = out / f"{R}_ring_of_one_kernel_stats.csv"
 if ring.exists():
