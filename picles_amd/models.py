@@ -56,11 +56,12 @@ class LazyState:
     def _valid(self):
         # the mirror is current only while nothing has touched the device field behind our back (HipModel.gen counts the
         # calls that can; a backend without the counter is re-read every time)
-        return self.host_valid and self._host is not None and getattr(self._b, "gen", None) == self._gen
+        g = getattr(self._b, "gen", None)
+        return self.host_valid and self._host is not None and g is not None and g == self._gen
 
     def _pull(self):
         if self.zeroed and not self.dirty and getattr(self._b, "gen", None) == self._gen:
-            if not self._valid():
+            if self._host is None:
                 self._host = np.zeros(self.shape)
                 self.host_valid = True
             return self._host

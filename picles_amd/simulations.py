@@ -1,12 +1,12 @@
 """Simulation / run! / init_particles! (reference: src/Simulations/simulation.jl:11-98,
-src/Simulations/run.jl:36-146,199-247; CashStore: storing.jl:7-25).  HDF5 StateStore is out of
-scope."""
+src/Simulations/run.jl:36-146,199-247; CashStore: storing.jl:7-25; the HDF5 StateStore is picles_amd/storing.py)."""
 from __future__ import annotations
 
 import time
 
 import numpy as np
 
+from .storing import NpyStateStore, StateStore, make_state_store
 from .timesteppers import time_step
 
 
@@ -16,39 +16,29 @@ class CashStore:
         self.iteration = 1
 
 
-class StateStore:
-    """Counterpart of the reference's HDF5 StateStore (storing.jl:36-62,109-119): the dataset
-    `waves/data[time, x, y, state]` with `var_names = ["e","m_x","m_y"]` and the coordinate vectors.
-    HDF5 bindings are not available in this image, so the same logical layout is written as a NumPy
-    `.npy` memory map plus a JSON side-car; the device→host path (asynchronous snapshot ring) is what
-    the library provides either way."""
-
-    def __init__(self, path, time, x, y, name="state"):
-        import json
-        from pathlib import Path
-        self.dir = Path(path)
-        self.dir.mkdir(parents=True, exist_ok=True)
-        self.shape = (len(time), len(x), len(y), 3)
-        self.data = np.lib.format.open_memmap(self.dir / f"{name}.waves.data.npy", mode="w+", dtype=np.float64, shape=self.shape)
-        (self.dir / f"{name}.json").write_text(json.dumps(
-            {"group": "waves", "dims": ["time", "x", "y", "state"], "var_names": ["e", "m_x", "m_y"],
-             "time": list(map(float, time)), "x": list(map(float, x)), "y": list(map(float, y))}))
-        self.iteration = 0
-
-    def write(self, state):
-        self.data[self.iteration] = state
-        self.iteration += 1
-
-    def close(self):
-        self.data.flush()
-
-
-def init_state_store(sim, save_path, name="state"):
-    """init_state_store!(sim, save_path) (storing.jl:83-104)"""
+def init_state_store(sim, save_path, name="state", format="auto"):
+    """init_state_store!(sim, save_path) (storing.jl:83-104): `time` runs to stop_time + Δt (run! takes one step past stop_time).
+    format "hdf5" = the reference's file (picles_amd/storing.py), "npy" = the same layout as a NumPy memory map, "auto" = hdf5
+    where a libhdf5 loads"""
     g = sim.model.grid
     times = np.arange(0.0, sim.stop_time + sim.Δt + 0.5 * sim.Δt, sim.Δt)
-    sim.store = StateStore(save_path, times, g.data.x[:, 0], g.data.y[0, :], name=name)
+    sim.store = make_state_store(save_path, times, g.data.x[:, 0], g.data.y[0, :], name=name, format=format)
     return sim.store
+
+
+def push_state_to_storage(sim, i=None):
+    """push_state_to_storage!(sim; i) (storing.jl:109-119)"""
+    sim.store.write(sim.model.State, i=i)
+
+
+def reset_state_store(sim, value=0.0):
+    """reset_state_store!(sim; value) (storing.jl:127-131)"""
+    sim.store.reset(value)
+
+
+def close_store(sim):
+    """close_store!(sim) (storing.jl:178-180)"""
+    sim.store.close()
 
 
 class Simulation:
@@ -82,15 +72,23 @@ def initialize_simulation(sim: Simulation):
 
 
 def reset_simulation(sim: Simulation):
+    """reset_simulation!(sim) (run.jl:154-181): clock to zero, particles re-seeded, **State cleared** (so a following run!
+    stores zeros as its initial state — the reference's behaviour), the state store reset"""
+    sim.running = False
+    sim.run_wall_time = 0.0
     sim.model.clock.time = 0.0
     sim.model.clock.iteration = 0
-    initialize_simulation(sim)
+    init_particles(sim.model, defaults=sim.model.ODEdefaults, verbose=sim.verbose)
+    sim.model.State.fill(0.0)
+    sim.initialized = True
+    if isinstance(sim.store, (StateStore, NpyStateStore)):
+        sim.store.reset()
 
 
 def run(sim: Simulation, store=False, pickup=False, cash_store=False, debug=False):
     """run!(sim) (run.jl:36-122): note `stop_time >= clock.time`, i.e. one step past stop_time."""
     t0 = time.perf_counter_ns()
-    if store and not isinstance(sim.store, StateStore):
+    if store and not isinstance(sim.store, (StateStore, NpyStateStore)):
         raise ValueError("call init_state_store(sim, path) before run(sim, store=True)")
     ring = store and hasattr(sim.model.backend, "store_init")
     if not sim.initialized:
