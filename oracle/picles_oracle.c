@@ -1810,6 +1810,7 @@ PO_EXPORT void picles_oracle_math(int32_t fn, int64_t n, const double *x, const 
         case 7: out[i] = o_log_coarse(x[i]); break;
 #ifdef PO_PMATH
         case 8: out[i] = pm_rsqrt(x[i]); break;
+        case 9: out[i] = pm_div_1e6(x[i]); break;      /* the kernels' n / 1e6 (three operations), for the exhaustive comparison */
 #endif
         default: out[i] = NAN;
         }

@@ -295,7 +295,7 @@ PM_HD void index_weight(double zp, int &b, double &w_hi)
 {
     double fb = __builtin_floor(zp);
     b = (int)fb;
-    w_hi = __builtin_rint((zp - fb) * 1e6) / 1e6;
+    w_hi = pm_div_1e6(__builtin_rint((zp - fb) * 1e6));      /* the bits of rint(...) / 1e6 */
 }
 
 /* RHS in kernel order: d(lne), d(c̄x), d(c̄y).  The position tendencies are c̄x/Δx, c̄y/Δy
@@ -336,7 +336,7 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     if (!(targ <= -40.0)) t = pm_exp_bounded(targ);
     double t1 = 1.0 + t;
     double t12 = t1 * t1;
-    double rHD = 1.0 / (hp * t12);
+    double rHD = pm_rcp_plain(hp * t12);     /* hp in [1, 1 + e^700], t12 in [1, 4]: a plain operand (or NaN) */
     double H = t12 * rHD;
     double D = 1.0 - ((5.0 * t) * hp) * rHD;
     double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, Ek = 0.0;
@@ -418,7 +418,7 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     double t = (targ <= -40.0) ? 0.0 : pm_exp(targ);
     double t1 = 1.0 + t;
     double t12 = t1 * t1;
-    double rHD = 1.0 / (hp * t12);
+    double rHD = pm_rcp_plain(hp * t12);
     double H = t12 * rHD;
     double D = 1.0 - ((5.0 * t) * hp) * rHD;
     double aH = alpha2 * H;
@@ -575,7 +575,7 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     S = PM_FMA(n2, n2, S);
     S = PM_FMA(n3, n3, S);
     S = PM_FMA(n4, n4, S);
-    double rp = 1.0 / pp;
+    double rp = pm_rcp_plain(pp);     /* see the explicit pair's error norm */
     return (S * 0.2) * (rp * rp);
 }
 
@@ -794,7 +794,10 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             S = PM_FMA(n2, n2, S);
             S = PM_FMA(n3, n3, S);
             S = PM_FMA(n4, n4, S);
-            double rp = 1.0 / pp;
+            /* every scale is >= abstol, so pp >= abstol⁵ is a plain operand while the state is finite and moderate.  Beyond
+             * that (pp = inf or NaN, or within a factor four of overflow) S has overflowed as well — each n_i carries four of
+             * the five scales — and EE2 comes out NaN (inf·0) or 0 from either form of the reciprocal */
+            double rp = pm_rcp_plain(pp);
             EE2 = (S * 0.2) * (rp * rp);
         }
 #undef ST3

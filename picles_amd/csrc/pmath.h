@@ -56,6 +56,51 @@ PM_HD double pm_fmax(double a, double b) { return __builtin_fmax(a, b); }
 /* 2^k for -1022 <= k <= 1023 */
 PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
 
+/* 1/b and a/b for PLAIN operands — b finite and normal with |b| <= 2^1021, a finite, the quotient neither overflowing nor
+ * denormal — as the call sites below guarantee by construction.  On the device this is the compiler's own expansion of an IEEE
+ * fp64 division (v_rcp_f64 seed, two Newton steps, one residual correction) without its range scaling (2 x v_div_scale) and its
+ * special-case fix-up (v_div_fmas, v_div_fixup), which are the identity for plain operands: 7 / 8 issue slots instead of 11 / 12,
+ * and the same correctly rounded quotient, i.e. the same bits as `/` on the host.  A NaN operand gives a NaN either way; the
+ * one deviation inside the plain range is the sign of a zero quotient from a = -0 (+0 here) — the numerators at the call sites
+ * are differences m - 1.0, which are never -0.
+ * (tests/test_gpu_pmath.py compares the device results with the host's division bit by bit.) */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double pm_rcp_plain(double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = PM_FMA(-b, y, 1.0);
+    y = PM_FMA(y, e, y);
+    e = PM_FMA(-b, y, 1.0);
+    y = PM_FMA(y, e, y);
+    e = PM_FMA(-b, y, 1.0);
+    return PM_FMA(e, y, y);
+}
+__device__ __forceinline__ double pm_div_plain(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = PM_FMA(-b, y, 1.0);
+    y = PM_FMA(y, e, y);
+    e = PM_FMA(-b, y, 1.0);
+    y = PM_FMA(y, e, y);
+    double q = a * y;
+    double r = PM_FMA(-b, q, a);
+    return PM_FMA(r, y, q);
+}
+#else
+PM_HD double pm_rcp_plain(double b) { return 1.0 / b; }
+PM_HD double pm_div_plain(double a, double b) { return a / b; }
+#endif
+
+/* n / 1e6 for an integer-valued 0 <= n <= 1e6 (round(x, digits = 6) of a cell fraction): q = n·RN(1e-6) is within an ulp,
+ * one residual and one correction make it the correctly rounded quotient (Markstein) — verified for every one of the 1 000 001
+ * arguments against the division (tests/test_pmath.py::test_div_1e6_exhaustive).  3 issue slots instead of 12. */
+PM_HD double pm_div_1e6(double n)
+{
+    double q = n * 1e-6;
+    double r = PM_FMA(-1e6, q, n);
+    return PM_FMA(r, 1e-6, q);
+}
+
 /* 2^(j/512), j = 0..511, correctly rounded, and the reduction constants (generated) */
 #include "pm_exp_tab.h"
 
@@ -163,7 +208,7 @@ PM_HD double pm_log(double x)
     double m = pm_from_bits(ux);
     double f = m - 1.0;
     double hfsq = 0.5 * f * f;
-    double s = f / (2.0 + f);
+    double s = pm_div_plain(f, 2.0 + f);      /* 2 + f in [1.70, 2.42] whatever x is (m is rebuilt from the mantissa bits) */
     double z = s * s;
     double w = z * z;
     double t1 = w * PM_FMA(w, PM_FMA(w, Lg6, Lg4), Lg2);
@@ -208,7 +253,7 @@ PM_HD double pm_log_coarse(double x)
     hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
     double m = pm_from_bits(((uint64_t)hx << 32) | (ux & 0xffffffffULL));
     double f = m - 1.0;
-    double s = f / (2.0 + f);
+    double s = pm_div_plain(f, 2.0 + f);      /* 2 + f in [1.70, 2.42] */
     double z = s * s;
     double p = PM_FMA(z, PM_FMA(z, PM_FMA(z, PM_FMA(z, 2.0 / 9.0, 2.0 / 7.0), 2.0 / 5.0), 2.0 / 3.0), 2.0);
     return PM_FMA((double)k, 6.93147180559945286227e-01, s * p);

@@ -1,0 +1,20 @@
+"""pmath.h on the device against pmath.h on the host, function by function and bit by bit (tests/native/gpu_pmath_check.hip):
+4 M operands each for the short division sequences (against the IEEE division, over the operand ranges their call sites
+guarantee and a wide plain range), n / 1e6, exp, log, the controller's coarse log and the reciprocal square root."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.gpu
+def test_device_math_equals_host_math_bitwise(tmp_path):
+    exe = tmp_path / "gpu_pmath_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                    "-I", str(ROOT / "picles_amd" / "csrc"), str(ROOT / "tests" / "native" / "gpu_pmath_check.hip"), "-o", str(exe)],
+                   check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" 0 mismatches") == 7, r.stdout

@@ -77,3 +77,11 @@ def test_pow_tanh_cosh():
 def test_libm_backend_is_glibc():
     x = np.linspace(-5, 5, 101)
     assert np.allclose(O.math_fn(0, x, kind="libm"), np.exp(x), rtol=4e-16, atol=0)
+
+
+def test_div_1e6_exhaustive():
+    """round(x, digits = 6) = rint(x·1e6)/1e6 (ParticleInCell.jl:58-71): the kernels replace the division by q = n·1e-6 plus one
+    residual correction (pmath.h pm_div_1e6).  Every possible argument — the integers 0 … 1 000 000 — against the division"""
+    n = np.arange(0, 1_000_001, dtype=np.float64)
+    got = O.math_fn(9, n)
+    np.testing.assert_array_equal(got.view(np.uint64), (n / 1e6).view(np.uint64))
