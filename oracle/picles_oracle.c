@@ -324,7 +324,7 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double rc = ph->r_g * o_rsqrt(c2);
     double minv = fmin(rc, 10.0);            /* IEEE minNum: a NaN rc gives the floor */
     double wp = (0.5 * G0) * minv;
-    double kp = (0.25 * G0) * (minv * minv);
+    double m2 = minv * minv;                 /* k_p = (g/4) m2: its powers are taken on m2, K = (g/4)⁴ rides in the constants */
     double rc2 = rc * rc;
     double alpha2 = fmin((0.25 * U2) * rc2, 250000.0);   /* α² = min(U/(2 c_gp), 500)²: the wind speed itself is never formed */
     /* dot / cross products on the raw c̄; the 1/r_g factors ride in the constants */
@@ -343,41 +343,42 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double t12 = t1 * t1;
     double rHD = 1.0 / (hp * t12);
     double H = t12 * rHD;
-    double D = 1.0 - ((5.0 * t) * hp) * rHD;
+    double D = PO_FMA(-((5.0 * t) * hp), rHD, 1.0);
 
-    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, Ek = 0.0;
     double aH = alpha2 * H;
     int n_is_2 = (k->n == 2.0);
+    /* constants of the kernel order (picles_hip.hip, picles_create) */
+    const double g4 = 0.25 * G0, g42 = g4 * g4, K = g42 * g42;
+    const double ie2 = k->inv_eT * k->inv_eT, inv_eT4 = ie2 * ie2;
+    const double KeT4 = K * inv_eT4, KrCa = (K * ph->r_g) * ph->C_alpha;
+    const double Cdir = ph->C_phi * (2.0 * (k->inv_rg * k->inv_rg));
+    double Ek8 = 0.0;
     if ((ph->dissipation && n_is_2) || ph->peak_shift) {
-        double k2 = kp * kp;
-        Ek = o_exp(2.0 * lne) * (k2 * k2);
+        double m4 = m2 * m2;
+        Ek8 = o_exp(2.0 * lne) * (m4 * m4);
     }
-    if (ph->input) It = ph->C_e * aH;
+    double Dt = 0.0;
     if (ph->dissipation) {
         if (n_is_2) {
-            double ie2 = k->inv_eT * k->inv_eT;
-            Dt = Ek * (ie2 * ie2);
+            Dt = Ek8 * KeT4;
         } else {
-            double ke = kp * k->inv_eT;
+            double ke = (g4 * m2) * k->inv_eT;
             Dt = o_exp(k->n * lne) * o_pow(ke, 2.0 * k->n);
         }
     }
-    if (ph->peak_shift) Scg = (ph->C_alpha * D) * Ek;
+    double IDt = PO_FMA(ph->input ? ph->C_e : 0.0, aH, -Dt);
+    double wrS = 0.0;
+    if (ph->peak_shift) wrS = (wp * D) * (Ek8 * KrCa);
+    double Sd = 0.0;
     if (ph->direction) {
-        double s2;
-        if (U2 == 0.0 || c2 == 0.0)
-            s2 = 0.0;
-        else
-            s2 = (((2.0 * (k->inv_rg * k->inv_rg)) * crsc) * dotc) * (rc2 * (1.0 / U2));
+        if (!(U2 == 0.0 || c2 == 0.0)) Sd = ((crsc * dotc) * (rc2 * aH)) * (Cdir * (1.0 / U2));
         {   /* opt-in dead band (picles_phys.dir_deadband) */
             double db2 = ph->dir_deadband * ph->dir_deadband;
-            if (db2 > 0.0 && crsc * crsc <= db2 * (U2 * c2)) s2 = 0.0;
+            if (db2 > 0.0 && crsc * crsc <= db2 * (U2 * c2)) Sd = 0.0;
         }
-        Sd = (ph->C_phi * aH) * s2;
     }
-    double wrS = (wp * ph->r_g) * Scg;
     if (M->pc) Sd = Sd + cx * M->pc[idx];   /* great-circle term rides on the direction term */
-    dz[0] = PO_FMA(wp, It - Dt, wrS);
+    dz[0] = PO_FMA(wp, IDt, wrS);
     dz[1] = PO_FMA(cy, Sd, -(cx * wrS));
     dz[2] = -PO_FMA(cx, Sd, cy * wrS);
     if (ph->propagation) {
@@ -798,9 +799,12 @@ static void po_rhs_jvp(const po_model *M, int64_t idx, const double z[5], double
     double Sd = ph->direction ? (ph->C_phi * aH) * s2 : 0.0;
     double wrS = (wp * ph->r_g) * Scg;
     double Sdm = Sd + (M->pc ? cx * pc : 0.0);
-    f[0] = PO_FMA(wp, It - Dt, wrS);
-    f[1] = PO_FMA(cy, Sdm, -(cx * wrS));
-    f[2] = -PO_FMA(cx, Sdm, cy * wrS);
+    {   /* the primal handed back is the RHS itself; the intermediates above (the association the kernel's rhs3_jvp uses, an
+         * ulp away from po_rhs_kernel's in places) only feed the tangents */
+        double dz[5];
+        po_rhs_kernel(M, idx, z, u, v, dz);
+        f[0] = dz[0]; f[1] = dz[1]; f[2] = dz[2];
+    }
     /* tangents */
     for (int q = 0; q < ns; q++) {
         const double dL = seeds[q][0], dcx = seeds[q][1], dcy = seeds[q][2], du = seeds[q][3], dv = seeds[q][4];

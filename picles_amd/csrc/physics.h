@@ -32,6 +32,7 @@ struct KParams {
     double r_g, inv_rg, C_alpha, C_phi, C_e;
     double p, n, neg2p, inv_eT;
     double inv_eT4, half_inv_rg, two_inv_rg2;   /* (1/e_T)⁴, 1/(2 r_g), 2/r_g² */
+    double KeT4, KrCa, Cdir;                    /* K/e_T⁴, K r_g C_α with K = (g/4)⁴ (k_p⁴ = K·(1/c_gp)⁸); 2 C_φ/r_g² */
     double inv_dx, inv_dy;
     double deadband2;       /* dir_deadband² (0 = off) */
     int propagation, input, dissipation, peak_shift, direction, n_is_2;
@@ -204,14 +205,16 @@ struct PStats {
  * For time-constant winds they are computed once per particle-step (same arithmetic, hoisted). */
 struct WindD {
     double u, v, U2, invU2, qU2;   /* U² = u²+v², 1/U², U²/4 — the wind speed itself is never needed (α enters as α²) */
+    double sK;                     /* 2 C_φ/(r_g² U²): the wind's share of the direction term */
 };
-PM_HD void wind_derive(double u, double v, WindD &d)
+PM_HD void wind_derive(const KParams &P, double u, double v, WindD &d)
 {
     d.u = u;
     d.v = v;
     d.U2 = PM_FMA(u, u, v * v);
     d.invU2 = 1.0 / d.U2;
     d.qU2 = 0.25 * d.U2;
+    d.sK = P.Cdir * d.invU2;
 }
 PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double &v)
 {
@@ -229,7 +232,7 @@ PM_HD void wind_stage(const KParams &P, const Wind &w, double t, WindD &d)
 {
     if (!STATIC) {
         double s = (t - P.tw0) * P.inv_dtw;
-        wind_derive(PM_FMA(w.du, s, w.u0), PM_FMA(w.dv, s, w.v0), d);
+        wind_derive(P, PM_FMA(w.du, s, w.u0), PM_FMA(w.dv, s, w.v0), d);
     }
 }
 
@@ -316,7 +319,7 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double rc = P.r_g * pm_rsqrt(c2);
     double minv = pm_fmin(rc, 10.0);
     double wp = (0.5 * PK_G0) * minv;
-    double kp = (0.25 * PK_G0) * (minv * minv);
+    double m2 = minv * minv;                            /* k_p = (g/4)·m2; its powers are taken on m2, the constant rides below */
     double rc2 = rc * rc;
     double alpha2 = pm_fmin(W.qU2 * rc2, 250000.0);     /* α² = min(U/(2 c_gp), 500)² */
     /* dot and cross products on the raw c̄ (the 1/r_g factors ride in the constants below);
@@ -338,40 +341,41 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double t12 = t1 * t1;
     double rHD = pm_rcp_plain(hp * t12);     /* hp in [1, 1 + e^700], t12 in [1, 4]: a plain operand (or NaN) */
     double H = t12 * rHD;
-    double D = 1.0 - ((5.0 * t) * hp) * rHD;
-    double It = 0.0, Dt = 0.0, Scg = 0.0, Sd = 0.0, Ek = 0.0;
+    double D = PM_FMA(-((5.0 * t) * hp), rHD, 1.0);
     const double aH = alpha2 * H;
+    /* e² k_p⁴ / K = e² (1/c_gp)⁸, K = (g/4)⁴: shared by the dissipation and the peak shift, which carry K in their constants */
+    double Ek8 = 0.0;
     if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) {
-        double k2 = kp * kp;
-        Ek = pm_exp(2.0 * lne) * (k2 * k2);      /* e² k_p⁴: shared by the dissipation and the peak shift */
+        double m4 = m2 * m2;
+        Ek8 = pm_exp(2.0 * lne) * (m4 * m4);
     }
-    if (FAST || P.input) It = P.C_e * aH;
+    /* Ĩ - D̃ = C_e α² H - e² k_p⁴/e_T⁴ in one fused step (a switched-off term is an exact zero: C_e -> 0, D̃ -> 0) */
+    double Dt = 0.0;
     if (FAST || P.dissipation) {
         if (FAST || P.n_is_2) {
-            Dt = Ek * P.inv_eT4;
+            Dt = Ek8 * P.KeT4;
         } else {
-            double ke = kp * P.inv_eT;
+            double ke = ((0.25 * PK_G0) * m2) * P.inv_eT;
             Dt = pm_exp(P.n * lne) * pm_pow(ke, 2.0 * P.n);
         }
     }
-    if (FAST || P.peak_shift) Scg = (P.C_alpha * D) * Ek;
+    const double IDt = PM_FMA((FAST || P.input) ? P.C_e : 0.0, aH, -Dt);
+    /* ω_p r_g S_cg = ω_p r_g C_α Δ e² k_p⁴ */
+    double wrS = 0.0;
+    if (FAST || P.peak_shift) wrS = (wp * D) * (Ek8 * P.KrCa);
+    double Sd = 0.0;
     if (FAST || P.direction) {
-        double s2;
-        if (W.U2 == 0.0 || c2 == 0.0)
-            s2 = 0.0;
-        else
-            s2 = ((P.two_inv_rg2 * crsc) * dotc) * (rc2 * W.invU2);
+        /* S_dir = C_φ α² H sin 2(θ_c - θ_w) = [2 C_φ/(r_g² U²)]·(c̄ × u)(c̄ · u)·(1/c_gp²)·α² H; 0 for a vanishing wind or c̄ */
+        if (!(W.U2 == 0.0 || c2 == 0.0)) Sd = ((crsc * dotc) * (rc2 * aH)) * W.sK;
         /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned.  Only the general-physics
          * kernels carry it (a run-time test here costs the specialised kernel 2.6 %, measured; a compile-time flavour of it
          * doubled the kernel count): a context with a dead band runs the general kernels */
         if (!FAST && P.deadband2 > 0.0) {
-            if (crsc * crsc <= P.deadband2 * (W.U2 * c2)) s2 = 0.0;
+            if (crsc * crsc <= P.deadband2 * (W.U2 * c2)) Sd = 0.0;
         }
-        Sd = (P.C_phi * aH) * s2;
     }
-    double wrS = (wp * P.r_g) * Scg;
     if (METRIC) Sd = Sd + cx * pc;   /* great-circle term S_sphere = PC(c̄x) = c̄x·coef rides on S_dir */
-    d.lne = PM_FMA(wp, It - Dt, wrS);
+    d.lne = PM_FMA(wp, IDt, wrS);
     d.cx = PM_FMA(cy, Sd, -(cx * wrS));
     d.cy = -PM_FMA(cx, Sd, cy * wrS);
 }
@@ -671,7 +675,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     constexpr bool has2 = TSIT;   /* Tsit5: a72, e2 != 0 (compile-time: the DP5 instruction stream is untouched) */
     constexpr double beta1 = TSIT ? PI_BETA1_TSIT : PI_BETA1, beta2 = TSIT ? PI_BETA2_TSIT : PI_BETA2;
     double tr = 0.0;
-    if (STATIC) wind_derive(w.u0, w.v0, W);
+    if (STATIC) wind_derive(P, w.u0, w.v0, W);
     else wind_stage<false>(P, w, t_start, W);
     rhs3<FAST, METRIC>(P, z.lne, z.cx, z.cy, W, k1, pc);
     st.rhs++;

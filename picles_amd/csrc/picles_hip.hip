@@ -586,6 +586,12 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.inv_eT4 = (P.inv_eT * P.inv_eT) * (P.inv_eT * P.inv_eT);
     P.half_inv_rg = 0.5 * P.inv_rg;
     P.two_inv_rg2 = 2.0 * (P.inv_rg * P.inv_rg);
+    {
+        const double k1 = 0.25 * PK_G0, k2 = k1 * k1, K = k2 * k2;      /* k_p⁴ = K (1/c_gp)⁸ */
+        P.KeT4 = K * P.inv_eT4;
+        P.KrCa = (K * P.r_g) * P.C_alpha;
+        P.Cdir = P.C_phi * P.two_inv_rg2;
+    }
     P.inv_dx = 1.0 / g->dx; P.inv_dy = 1.0 / g->dy;
     P.deadband2 = p->dir_deadband * p->dir_deadband;
     P.propagation = p->propagation; P.input = p->input; P.dissipation = p->dissipation;
