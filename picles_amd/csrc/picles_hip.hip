@@ -42,6 +42,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1456,19 +1457,29 @@ struct RcclApi {
     void *handle = nullptr;
 };
 
+/* RCCL by default (the copy torch.distributed has loaded, if any).  PICLES_CCL_LIB names another library that exports the same
+ * eight entry points — an MPI-backed shim, or the thread loopback the tests use to run the ring with several ranks on one GPU. */
 static RcclApi *rccl_api(std::string &err)
 {
     static RcclApi api;
     static bool tried = false;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (api.handle) return &api;
-    if (tried) { err = "RCCL could not be loaded"; return nullptr; }
+    if (tried) { err = "the communication library could not be loaded"; return nullptr; }
     tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;    /* the copy already loaded, if any */
-    if (!h) for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) { err = std::string("dlopen(librccl.so.1): ") + dlerror(); return nullptr; }
-#define RSYM(f) do { api.f = (decltype(api.f))dlsym(h, "nccl" #f); if (!api.f) { err = "librccl lacks nccl" #f; return nullptr; } } while (0)
+    const char *over = getenv("PICLES_CCL_LIB");
+    if (over && *over) {
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { err = std::string("dlopen(PICLES_CCL_LIB=") + over + "): " + dlerror(); return nullptr; }
+    } else {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;    /* the copy already loaded, if any */
+        if (!h) for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) { err = std::string("dlopen(librccl.so.1): ") + dlerror(); return nullptr; }
+    }
+#define RSYM(f) do { api.f = (decltype(api.f))dlsym(h, "nccl" #f); if (!api.f) { err = "the communication library lacks nccl" #f; return nullptr; } } while (0)
     RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(CommDestroy); RSYM(GroupStart); RSYM(GroupEnd); RSYM(Send); RSYM(Recv);
     RSYM(GetErrorString);
 #undef RSYM
