@@ -333,16 +333,31 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     double sginv2 = fmin(rc2, 1e8);
     double ap = ((0.5 * k->inv_rg) * dotc) * sginv2;
     double ya = ap - 0.85;
-    /* one reciprocal for H_β and Δ_β: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t(1+eH) r;
-     * t = exp(-20|ya|) is taken as 0 once 5t < 2^-54 (Δ rounds to 1); eH stays finite (argument <= 700) */
-    double harg = (-2.0 * k->p) * ya;
-    double hp = 1.0 + o_exp((harg > 700.0) ? 700.0 : harg);
-    double targ = -20.0 * fabs(ya);
-    double t = (targ <= -40.0) ? 0.0 : o_exp(targ);
-    double t1 = 1.0 + t;
-    double t12 = t1 * t1;
-    double rHD = 1.0 / (hp * t12);
-    double H = t12 * rHD;
+    /* one reciprocal for H_β and Δ_β: r = 1/(hp (1+t)²), H = (1+t)² r, Δ = 1 - 5t hp r */
+    double hp, t, H, rHD, t12;
+    if (k->p == 0.75) {
+        /* 2p = 3/2: eH = exp(-2p ya) = w^(±3) and t = exp(-20|ya|) = w^40 with w = exp(-|ya|/2); s = w³, hp = 1 + s,
+         * H = 1/(1+s) for ya >= 0 and s/(1+s) below (physics.h rhs3) */
+        double w = o_exp(-0.5 * fabs(ya));
+        double w2 = w * w, s3 = w2 * w;
+        double w4 = w2 * w2, w5 = w4 * w, w10 = w5 * w5, w20 = w10 * w10;
+        t = w20 * w20;
+        hp = 1.0 + s3;
+        double t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = 1.0 / (hp * t12);
+        H = (t12 * rHD) * ((ya >= 0.0) ? 1.0 : s3);
+    } else {
+        /* general p: t = exp(-20|ya|) is taken as 0 once 5t < 2^-54 (Δ rounds to 1); eH stays finite (argument <= 700) */
+        double harg = (-2.0 * k->p) * ya;
+        hp = 1.0 + o_exp((harg > 700.0) ? 700.0 : harg);
+        double targ = -20.0 * fabs(ya);
+        t = (targ <= -40.0) ? 0.0 : o_exp(targ);
+        double t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = 1.0 / (hp * t12);
+        H = t12 * rHD;
+    }
     double D = PO_FMA(-((5.0 * t) * hp), rHD, 1.0);
 
     double aH = alpha2 * H;

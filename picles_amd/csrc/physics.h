@@ -36,6 +36,7 @@ struct KParams {
     double inv_dx, inv_dy;
     double deadband2;       /* dir_deadband² (0 = off) */
     int propagation, input, dissipation, peak_shift, direction, n_is_2;
+    int p_is_075;           /* 2p = 3/2 (q = -1/4, every reference script): exp(-2p y) and exp(-20|y|) are powers of one exponential */
     /* ODE settings */
     double abstol, reltol, dt0, dtmin;
     double inv_abstol;       /* 1/abstol: the error scale of a component that is exactly 0 */
@@ -330,17 +331,34 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double ap = (P.half_inv_rg * dotc) * sginv2;
     double ya = ap - 0.85;
     /* H_β = 1/(1+eH), eH = exp(-2p ya);  Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).
-     * One reciprocal serves both: r = 1/((1+eH)(1+t)²), H = (1+t)² r, Δ = 1 - 5t (1+eH) r.
-     * For 20|ya| >= 40, 5t < 2^-54 and Δ rounds to exactly 1.0: t is taken as 0 there (no exp),
-     * which also makes H = 1/(1+eH) to the last bit.  eH is kept finite so that 0·eH stays 0. */
-    double hp = 1.0 + pm_exp_finite(P.neg2p * ya);
-    double targ = -20.0 * pm_fabs(ya);
-    double t = 0.0;
-    if (!(targ <= -40.0)) t = pm_exp_bounded(targ);
-    double t1 = 1.0 + t;
-    double t12 = t1 * t1;
-    double rHD = pm_rcp_plain(hp * t12);     /* hp in [1, 1 + e^700], t12 in [1, 4]: a plain operand (or NaN) */
-    double H = t12 * rHD;
+     * One reciprocal serves both: r = 1/(hp (1+t)²), H = (1+t)² r, Δ = 1 - 5t hp r. */
+    double hp, t, H, rHD, t12;
+    if (FAST || P.p_is_075) {
+        /* 2p = 3/2: both exponentials are powers of w = exp(-|ya|/2) — eH = w^(±3), t = w^40 — so ONE exponential and seven
+         * multiplications serve both (the second exponential cost 16 issue slots).  With s = w³ <= 1: for ya >= 0, eH = s and
+         * H = 1/(1+s); for ya < 0, eH = 1/s and H = s/(1+s): the reciprocal is that of hp = 1 + s in [1, 2] either way, and Δ,
+         * which depends on t alone, keeps its form.  For 20|ya| >= 40, 5t < 2^-54: 1 + t and Δ round to exactly 1. */
+        double w = pm_exp(-0.5 * pm_fabs(ya));
+        double w2 = w * w, s3 = w2 * w;
+        double w4 = w2 * w2, w5 = w4 * w, w10 = w5 * w5, w20 = w10 * w10;
+        t = w20 * w20;
+        hp = 1.0 + s3;
+        double t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = pm_rcp_plain(hp * t12);            /* a plain operand in [1, 8] (or NaN) */
+        H = (t12 * rHD) * ((ya >= 0.0) ? 1.0 : s3);
+    } else {
+        /* general p: two exponentials.  For 20|ya| >= 40 t is taken as 0 (no exp), which also makes H = 1/(1+eH) to the last
+         * bit; eH is kept finite so that 0·eH stays 0 */
+        hp = 1.0 + pm_exp_finite(P.neg2p * ya);
+        double targ = -20.0 * pm_fabs(ya);
+        t = 0.0;
+        if (!(targ <= -40.0)) t = pm_exp_bounded(targ);
+        double t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = pm_rcp_plain(hp * t12);            /* hp in [1, 1 + e^700], t12 in [1, 4]: a plain operand (or NaN) */
+        H = t12 * rHD;
+    }
     double D = PM_FMA(-((5.0 * t) * hp), rHD, 1.0);
     const double aH = alpha2 * H;
     /* e² k_p⁴ / K = e² (1/c_gp)⁸, K = (g/4)⁴: shared by the dissipation and the peak shift, which carry K in their constants */

@@ -597,6 +597,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.deadband2 = p->dir_deadband * p->dir_deadband;
     P.propagation = p->propagation; P.input = p->input; P.dissipation = p->dissipation;
     P.peak_shift = p->peak_shift; P.direction = p->direction; P.n_is_2 = (P.n == 2.0);
+    P.p_is_075 = (P.p == 0.75);
     P.abstol = o->abstol; P.reltol = o->reltol; P.dt0 = o->dt0; P.dtmin = o->dtmin;
     P.inv_abstol = 1.0 / o->abstol;
     P.maxiters = o->maxiters; P.force_dtmin = o->force_dtmin;
@@ -955,7 +956,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     timing_begin(c, s, 0);
     {
         const KParams &P = c->P;
-        bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
+        bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
         Arrays A = arrays_for(c, c->cur, c->cur);
         StepLaunch L = {dim3(nblocks(nt, 256)), dim3(256), s, &c->P, &c->G, &A, 0.0, 0.0, c->clock, c->step_dt, r0, n0, r1, n1};
         launch_k_advance(L, fast, P.solver, P.wind_static != 0, c->A.pc != nullptr);      /* k_advance.hip */
@@ -974,7 +975,7 @@ static bool step_fusable(const picles_ctx *c, int flags)
 {
     if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps) return false;
     const KParams &P = c->P;
-    const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
+    const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
     /* the time-varying-wind and per-node-metric flavours of the fused kernel exist for the specialised physics */
     if (c->wind_grid_on) return fast;
     if (c->A.pc) return fast && P.wind_static != 0;
@@ -995,7 +996,7 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     const KParams &P = c->P;
     Arrays A = arrays_for(c, c->cur ^ 1, c->cur);
     /* specialised variant: every physics switch on and n = 2 (all reference scripts) */
-    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.deadband2 == 0.0;
+    bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
     timing_begin(c, s, 0);
     {
         StepLaunch L = {dim3(nblocks(nt, 256)), dim3(256), s, &c->P, &c->G, &A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1};
