@@ -25,7 +25,7 @@ sys.path.insert(0, str(ROOT))
 B_ALG = 64.0          # algorithmic HBM bytes per particle-step (SURVEY §8d / DESIGN.md)
 HBM_PEAK_GBPS = 8000.0
 FP64_PEAK_TFLOPS = 78.6
-FLOP_PER_RHS = 182.0  # executed fp64 flops per RHS evaluation, all-in: static count of the RK loop of k_step<FAST,DP5> (368 FMA, 322 MUL, 34 ADD per attempt of 6 evaluations)
+FLOP_PER_RHS = 175.0  # executed fp64 flops per RHS evaluation, all-in: static count of the RK loop of k_step<FAST,DP5> (332 FMA, 352 MUL, 34 ADD per attempt of 6 evaluations)
 
 
 def usable_cores():
