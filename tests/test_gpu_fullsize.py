@@ -200,3 +200,26 @@ def test_cfg4_box_4096x4096_x3_perturbed_winds():
     g, c = _parity(fn, 3, 1, 2e-2)
     S = g.State
     assert np.ptp(S[..., 0]) > 0.1 * S[..., 0].mean()            # neighbours differ
+
+
+# ------------------------------------------------------------------------------------------------ odd shape
+def test_odd_shape_1003x771_land_mixed_periodicity():
+    """none of the BASELINE sizes: Nx and Ny odd (waves straddle rows, the last workgroup is ragged), 3021 workgroups — not a
+    multiple of 8, so the XCD band mapping falls back to the identity —, periodic in x only, three land blocks (one across the
+    x wrap, one touching the open north edge), the model's periodic_boundary flag on (grid-boundary particles are stepped as a
+    second group), smoothly varying winds: bitwise against oracle B after each of six steps, observed and fused"""
+    from picles_amd.grids import TwoDCartesianGridMesh
+    nx, ny = max(1003 // SCALE, 67), max(771 // SCALE, 53)
+    dx = 2000.0
+
+    def fn():
+        cfg = configs.bench06_box(n=64, dx=dx, winds=configs.smooth_winds(9.0, -7.0, nx * dx, (ny - 1) * dx))
+        mask = np.ones((nx, ny), dtype=bool)
+        mask[nx // 5: nx // 5 + nx // 8, ny // 3: ny // 3 + ny // 10] = False
+        mask[-(nx // 40 + 2):, ny // 2: ny // 2 + ny // 7] = False; mask[: nx // 50 + 2, ny // 2: ny // 2 + ny // 7] = False   # across the x wrap
+        mask[nx // 2: nx // 2 + nx // 9, -(ny // 12 + 2):] = False                                                            # touches the open north edge
+        cfg.model["grid"] = TwoDCartesianGridMesh(dx * (nx - 1), nx, dx * (ny - 1), ny, mask=mask, periodic_boundary=(True, False))
+        return cfg
+    g, c = _parity(fn, 6, 2, 2e-2)
+    assert c["particles_advanced"] > 0 and c["max_reach"] >= 1
+    assert (np.asarray(g.grid.data.mask) == 3).sum() > 0 and (np.asarray(g.grid.data.mask) == 2).sum() > 0
