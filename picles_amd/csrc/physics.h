@@ -318,16 +318,16 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
      * Every use of rc passes a guard written so that a NaN (|c̄| = 0, inf or NaN) takes the guarded
      * branch: the speed floors 0.1 / 1e-4 of the reference become ceilings 10 / 1e4 on rc. */
     double rc = P.r_g * pm_rsqrt(c2);
-    double minv = pm_fmin(rc, 10.0);
+    double minv = pm_fmin_c(rc, 10.0);
     double wp = (0.5 * PK_G0) * minv;
     double m2 = minv * minv;                            /* k_p = (g/4)·m2; its powers are taken on m2, the constant rides below */
     double rc2 = rc * rc;
-    double alpha2 = pm_fmin(W.qU2 * rc2, 250000.0);     /* α² = min(U/(2 c_gp), 500)² */
+    double alpha2 = pm_fmin_c(W.qU2 * rc2, 250000.0);     /* α² = min(U/(2 c_gp), 500)² */
     /* dot and cross products on the raw c̄ (the 1/r_g factors ride in the constants below);
      * the cross product is two rounded products and one subtraction: exactly 0 for c̄x = c̄y, u = v */
     double dotc = PM_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
-    double sginv2 = pm_fmin(rc2, 1e8);      /* = (rc <= 1e4) ? rc² : 1e8, NaN -> 1e8 */
+    double sginv2 = pm_fmin_c(rc2, 1e8);      /* = (rc <= 1e4) ? rc² : 1e8, NaN -> 1e8 */
     double ap = (P.half_inv_rg * dotc) * sginv2;
     double ya = ap - 0.85;
     /* H_β = 1/(1+eH), eH = exp(-2p ya);  Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).
@@ -583,7 +583,7 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
 #undef WSOLVE
     const double h6 = h * (1.0 / 6.0);
 #define ROSE(c) (h6 * ((k1.c - 2.0 * k2.c) + k3.c))
-#define ERRS(a, b) PM_FMA(pm_fmax(pm_fabs(a), pm_fabs(b)), P.reltol, P.abstol)
+#define ERRS(a, b) PM_FMA(pm_fmax_abs(a, b), P.reltol, P.abstol)
     double s0 = ERRS(z.lne, un.lne), s1 = ERRS(z.cx, un.cx), s2 = ERRS(z.cy, un.cy);
     double s3 = ERRS(z.x, un.x), s4 = ERRS(z.y, un.y);
     double p2 = s0 * s1, p3 = p2 * s2, p4 = p3 * s3, pp = p4 * s4;
@@ -800,7 +800,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         ex = PM_FMA(TT(e7), un.cx, ex) * ipx; ey = PM_FMA(TT(e7), un.cy, ey) * ipy;
 #define E12(c) (has2 ? PM_FMA(TT(e2), k2.c, TT(e1) * k1.c) : TT(e1) * k1.c)
 #define ERRN(c) (h * PM_FMA(TT(e7), k7.c, PM_FMA(TT(e6), k6.c, PM_FMA(TT(e5), k5.c, PM_FMA(TT(e4), k4.c, PM_FMA(TT(e3), k3.c, E12(c)))))))
-#define ERRS(a, b) PM_FMA(pm_fmax(pm_fabs(a), pm_fabs(b)), P.reltol, P.abstol)
+#define ERRS(a, b) PM_FMA(pm_fmax_abs(a, b), P.reltol, P.abstol)
         /* EEst² = (1/5) Σ (e_i/s_i)² with ONE reciprocal (kernel order): every numerator is
          * multiplied by the other four scales, the sum is divided by (Π s_i)².  The controller
          * works on ln EEst = ½ ln EEst², so no square root is taken either. */
@@ -841,8 +841,8 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         if (accept) {
             st.acc++;
             double qi = pm_exp(PM_FMA(beta2, lq, -(beta1 * le))) * PI_GAMMA;
-            qi = pm_fmax(pm_fmin(qi, PI_QMAX), PI_QMIN);
-            lq = pm_fmax(le, PI_LNQOLDINIT);
+            qi = pm_fmax_c(pm_fmin_c(qi, PI_QMAX), PI_QMIN);
+            lq = pm_fmax_c(le, PI_LNQOLDINIT);
             dt = h * qi;
             z = un;
             k1 = k7;
@@ -851,7 +851,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         } else {
             st.rej++;
             double r = PI_GAMMA * pm_exp(-(beta1 * le));
-            r = pm_fmax(r, PI_QMIN);
+            r = pm_fmax_c(r, PI_QMIN);
             dt = h * r;
             if (!P.force_dtmin && h <= P.dtmin) { st.status |= 64 /*PICLES_ST_DTMIN*/; break; }
         }

@@ -52,6 +52,34 @@ PM_HD double pm_min(double a, double b) { return (a < b) ? a : b; }
  * (a compare + two selects otherwise); fmin / fmax on the host: identical results, NaNs included. */
 PM_HD double pm_fmin(double a, double b) { return __builtin_fmin(a, b); }
 PM_HD double pm_fmax(double a, double b) { return __builtin_fmax(a, b); }
+/* the same minNum / maxNum with the instruction written out on the device.  The compiler precedes v_min / v_max with a
+ * canonicalisation of every operand it cannot prove quiet (v_max x, x, x: loop-carried values, function results) — the
+ * instruction quiets a signalling NaN by itself in the kernels' IEEE mode, so those are wasted issue slots (16 per RK attempt,
+ * measured in the listing).  c: a wave-uniform bound (literal or kernel parameter). */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double pm_fmin_c(double a, double c)
+{
+    double r;
+    __asm__("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double pm_fmax_c(double a, double c)
+{
+    double r;
+    __asm__("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double pm_fmax_abs(double a, double b)      /* max(|a|, |b|) */
+{
+    double r;
+    __asm__("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+PM_HD double pm_fmin_c(double a, double c) { return __builtin_fmin(a, c); }
+PM_HD double pm_fmax_c(double a, double c) { return __builtin_fmax(a, c); }
+PM_HD double pm_fmax_abs(double a, double b) { return __builtin_fmax(__builtin_fabs(a), __builtin_fabs(b)); }
+#endif
 
 /* 2^k for -1022 <= k <= 1023 */
 PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
