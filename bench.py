@@ -98,7 +98,7 @@ def measured_traffic(args, world):
         if (world == 1 and d["config"]["n"] == args.n and tuple(d["config"]["winds"]) == tuple(args.winds)
                 and args.solver == "DP5" and args.deadband == 0.0 and not args.atomic):
             k = d["kernels"][d["dominant"]]
-            return k["hbm_read_bytes"] + k["hbm_write_bytes"], k.get("valu_busy"), k.get("valu_insts_per_wave")
+            return k["hbm_read_bytes"] + k["hbm_write_bytes"], k.get("valu_busy"), k.get("valu_insts_per_wave_steady", k.get("valu_insts_per_wave"))
     except Exception:
         pass
     return None, None, None

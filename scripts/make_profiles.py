@@ -36,7 +36,19 @@ def agg(d):
             seen.add((k, r["Dispatch_Id"])); n[k] += 1
     return {k: {a: b / n[k] for a, b in v.items()} for k, v in A.items()}, n
 
+def per_dispatch(d, counter):
+    """counter / SQ_WAVES of every dispatch, per kernel (the averages above mix the first steps of a run — six and five RK
+    attempts per particle while the step size ramps up — with the steady four-attempt steps the bench times)"""
+    rows = list(csv.DictReader(open(pick(d, "counter_collection.csv", "k_step"))))
+    V = collections.defaultdict(dict); W = collections.defaultdict(dict)
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if r["Counter_Name"] == counter: V[k][r["Dispatch_Id"]] = float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVES": W[k][r["Dispatch_Id"]] = float(r["Counter_Value"])
+    return {k: [round(V[k][i] / W[k][i]) for i in sorted(V[k], key=int) if W[k].get(i)] for k in V}
+
 sq, n1 = agg(f"{R}_pmc_sq"); fe, _ = agg(f"{R}_pmc_fetch"); wr, _ = agg(f"{R}_pmc_write")
+valu_pd = per_dispatch(f"{R}_pmc_sq", "SQ_INSTS_VALU")
 seedF, seedW = fe["k_seed"]["FETCH_SIZE"], wr["k_seed"]["WRITE_SIZE"]
 NP = 16777216
 lines = [f"# {R} PMC summary — `bench.py --steps 6 --warmup 2` (4096² periodic box, winds (10,10)), MI355X (scripts/collect_profiles.sh)", "",
@@ -58,6 +70,10 @@ for k in sq:
 dom = [k for k in res if k.startswith("k_step")][0]
 launch_ms = json.loads([l for l in open(out / f"{R}_bench.json") if l.startswith("{")][0])["roofline"]["avg_launch_ms"]
 tot = res[dom]["hbm_read_bytes"] + res[dom]["hbm_write_bytes"]
+lines += ["", f"VALU instructions per wave of `{dom}`, dispatch by dispatch: {valu_pd[dom]} — the first launches of a run take six and five RK",
+          "attempts per particle (the step size ramps up after seeding), the steady state the bench times takes four: the last value is the",
+          "one to hold against `ms_per_step`; the table's figure is the average over these dispatches."]
+res[dom]["valu_insts_per_wave_steady"] = valu_pd[dom][-1]
 lines += ["", f"Reading: the fused `{dom}` (one launch per model step) keeps the fp64 VALU issue port {res[dom]['valu_busy']*100:.0f} % busy — it is",
           f"VALU-issue bound. Its HBM traffic is {tot/1e9:.2f} GB per launch = {tot/NP:.0f} B/particle against the 64 B/particle algorithmic minimum",
           "(records 48 B in + 48 B out, winds 16 B, controller memory 8+8 B, status 4 B, flags 1 B; round 2 removed the 24 B State store — nobody can read State while a fused step is pending, flush() writes it); at the ≈5 TB/s this",
