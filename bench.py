@@ -107,8 +107,8 @@ def measured_traffic(args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)      # the first launches after seeding take six and five RK attempts per particle; from the fifth on the step is steady
     ap.add_argument("--grid-n", dest="n", type=int, default=4096, help="grid nodes per side")
     ap.add_argument("--winds", type=lambda s: tuple(float(x) for x in s.split(",")), default=(10.0, 10.0))
     ap.add_argument("--halo", type=int, default=2,
