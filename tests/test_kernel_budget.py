@@ -1,0 +1,37 @@
+"""Register / scratch budget of the fused step kernel, from the compiler's own resource report (hipcc cross-compiles gfx950
+without a GPU): the BASELINE flavour `k_step<FAST, DP5, STATIC>` must keep its three waves per SIMD with NO scratch — every
+change of the RHS or of pmath.h that lengthens a live range shows up here before it shows up as time."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="no hipcc")
+def test_baseline_kernel_keeps_three_waves_and_no_scratch(tmp_path):
+    src = ROOT / "picles_amd" / "csrc"
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-munsafe-fp-atomics",
+                        "-fPIC", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(src / "k_step_explicit.hip"),
+                        "-o", str(tmp_path / "k.o")], capture_output=True, text=True, cwd=src, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    usage = {}
+    for b in blocks:
+        name = b.split()[0]
+        get = lambda key: int(re.search(key + r": (\d+)", b).group(1))      # noqa: E731
+        usage[name] = dict(vgpr=get(r"VGPRs"), scratch=get(r"ScratchSize \[bytes/lane\]"), occ=get(r"Occupancy \[waves/SIMD\]"),
+                           vspill=get(r"VGPRs Spill"), sspill=get(r"SGPRs Spill"))
+    # template order: k_step<FAST, TSIT, STATIC, METRIC, AUTO>
+    base = usage["_Z6k_stepILb1ELb0ELb1ELb0ELb0EEv7KParams5GridP6Arraysddddiiii"]
+    assert base["occ"] == 3 and base["scratch"] == 0 and base["vspill"] == 0 and base["vgpr"] <= 168, base
+    assert base["sspill"] <= 48, base          # scalar spill code is VALU work (v_readlane / v_writelane): 44 -> 55 cost 2.3 % in round 2
+    for name, u in usage.items():
+        if name.startswith("_Z6k_stepILb1E"):          # every specialised-physics flavour runs at three waves per SIMD
+            assert u["occ"] == 3, (name, u)
+        if name.startswith("_Z6k_stepILb1ELb0E"):      # the DP5 flavours (device-sampled winds, per-node metric) stay within a few spilled registers
+            assert u["scratch"] <= 64, (name, u)
