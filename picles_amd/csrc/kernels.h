@@ -137,10 +137,12 @@ struct StepStats {
     int reach;
 };
 
+/* advance! in two halves: the step itself (on: the whole adaptive integration; off: the wind test) and the guards behind it.
+ * k_step re-reads its kernel arguments between the two (kargs_reload below). */
 template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
-__device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
-                                                double &dtn, double t_start, double DT, StepStats &S,
-                                                double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
+__device__ __forceinline__ int advance_core(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
+                                            double &dtn, double t_start, double DT, StepStats &S,
+                                            double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
 {
     int status = PICLES_ST_STEPPED;
     if (on) {
@@ -157,6 +159,12 @@ __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w,
             status |= PICLES_ST_SWITCHED_ON;
         }
     }
+    return status;
+}
+
+__device__ __forceinline__ int advance_guards(const KParams &P, const Wind &w, Vec5 &z, double &dtn, double t_start, double DT,
+                                              int status, StepStats &S)
+{
     if (pm_isnan(z.lne) || pm_isnan(z.cx) || pm_isnan(z.cy)) {
         double u, v;
         wind_at(P, w, t_start + DT, u, v);
@@ -178,6 +186,40 @@ __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w,
     if (status & PICLES_ST_CLAMPED) S.clamps = 1;
     if (status & PICLES_ST_MAXITERS) S.maxit = 1;
     return status;
+}
+
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
+__device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
+                                                double &dtn, double t_start, double DT, StepStats &S,
+                                                double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
+{
+    int status = advance_core<FAST, STATIC, METRIC, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, m11, m22, pc, asw);
+    return advance_guards(P, w, z, dtn, t_start, DT, status, S);
+}
+
+/* The kernel arguments of k_step as the kernarg segment lays them out (same order, natural alignment = the C struct rule;
+ * tests/test_kernel_budget.py holds the offsets against the compiler's own metadata).  k_step needs about forty scalars inside
+ * the RK loop and another thirty only behind it (record pointers, grid shape, guard thresholds); kept in SGPRs across the loop
+ * those overflow the scalar file and are spilled into VGPR lanes — v_writelane before the loop, v_readlane behind it: VALU slots,
+ * ~2.5 % of the step.  kargs_reload() hands out the argument block again behind an opaque barrier, so everything after the loop
+ * is loaded from the (scalar-cached) kernarg segment when it is used instead of living through the loop. */
+struct KStepArgs {
+    KParams P;
+    GridP G;
+    Arrays A;
+    double t_prev, DT_prev, t_start, DT;
+    int r0, n0, r1, n1;
+};
+static_assert(__builtin_offsetof(KStepArgs, G) == sizeof(KParams) && __builtin_offsetof(KStepArgs, A) % 8 == 0 &&
+              __builtin_offsetof(KStepArgs, t_prev) == __builtin_offsetof(KStepArgs, A) + sizeof(Arrays) &&
+              __builtin_offsetof(KStepArgs, r0) == __builtin_offsetof(KStepArgs, DT) + 8,
+              "KStepArgs must mirror the kernarg layout of k_step");
+typedef const KStepArgs *KStepArgsPtr;
+__device__ __forceinline__ KStepArgsPtr kargs_reload(void)
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();      /* constant address space */
+    __asm__ volatile("" : "+s"(p));      /* a pointer the compiler knows nothing about: no load through it moves above this line */
+    return (KStepArgsPtr)p;              /* the compiler's address-space inference turns the loads back into scalar loads */
 }
 
 /* scatter record of one advanced particle (ParticleToNode! inputs): charge, upper-node weights and

@@ -30,6 +30,21 @@ def test_baseline_kernel_keeps_three_waves_and_no_scratch(tmp_path):
     base = usage["_Z6k_stepILb1ELb0ELb1ELb0ELb0EEv7KParams5GridP6Arraysddddiiii"]
     assert base["occ"] == 3 and base["scratch"] == 0 and base["vspill"] == 0 and base["vgpr"] <= 168, base
     assert base["sspill"] <= 48, base          # scalar spill code is VALU work (v_readlane / v_writelane): 44 -> 55 cost 2.3 % in round 2
+    # kargs_reload() (kernels.h) reads the arguments behind the RK loop through a struct that must mirror the kernarg segment:
+    # hold its offsets against the compiler's metadata for the kernel (P, G, A, four doubles, four ints)
+    asm = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-munsafe-fp-atomics",
+                          "-fPIC", "--cuda-device-only", "-S", str(src / "k_step_explicit.hip"), "-o", "-"], capture_output=True, text=True,
+                         cwd=src, timeout=600).stdout
+    meta = asm[asm.find("amdhsa.kernels"):]
+    entry = meta[:meta.find("_Z6k_stepILb1ELb0ELb1ELb0ELb0EEv7KParams5GridP6Arraysddddiiii")]
+    offs = [(int(a), int(b)) for a, b in re.findall(r"\.offset:\s+(\d+)\s*\n\s*\.size:\s+(\d+)", entry[entry.rfind(".args:"):])][:11]
+    sizes = [b for _, b in offs]
+    assert sizes[3:] == [8, 8, 8, 8, 4, 4, 4, 4], offs
+    expect, pos = [], 0
+    for size, align in [(sizes[0], 8), (sizes[1], 4), (sizes[2], 8)] + [(8, 8)] * 4 + [(4, 4)] * 4:      # the C struct rule
+        pos = (pos + align - 1) // align * align
+        expect.append(pos); pos += size
+    assert [a for a, _ in offs] == expect, (offs, expect)
     for name, u in usage.items():
         if name.startswith("_Z6k_stepILb1E"):          # every specialised-physics flavour runs at three waves per SIMD
             assert u["occ"] == 3, (name, u)
