@@ -2,6 +2,7 @@
 `world` threads, one slab context each on the one GPU, joined into the library's NATIVE ring (picles_slab_comm_init /
 picles_slab_run_steps).  Prints one JSON line: the largest bitwise mismatch count against the single whole-grid context."""
 import json
+import os
 import sys
 import threading
 from pathlib import Path
@@ -19,6 +20,12 @@ from picles_amd.wind_emulator import GriddedWinds  # noqa: E402
 
 
 def box(case, solver):
+    if case == "box4096":      # the BASELINE box itself, winds perturbed so that neighbours differ (direction too, in a band of rows)
+        n = 4096 // int(os.environ.get("PICLES_FULLSIZE_SCALE", "1"))
+        P = 2000.0 * n
+        cfg = configs.box4096(n=n, n_steps=3, winds=configs.smooth_winds(10.0, 10.0, P, P, band=(0.48 * P, 0.52 * P)))
+        cfg.model["ODEsets"].solver = solver
+        return cfg
     n, dx = 96, 1500.0
     P = n * dx
     if case == "lattice":

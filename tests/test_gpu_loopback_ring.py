@@ -29,6 +29,7 @@ def loopback(tmp_path_factory):
     (3, "smooth", "AutoTsit5", 8, "3,5"),     # the reference's default solver; two run calls
     (4, "open", "DP5", 8, "8"),               # open y axis (end ranks have one neighbour), land across a slab boundary
     (3, "lattice", "DP5", 6, "2,4"),          # device-sampled time-varying winds: the sampler is ordered against both ring streams
+    (8, "box4096", "DP5", 3, "1,2"),          # the BASELINE box in the decomposition of the 8-GPU run: eight slabs of 512 full-width rows
 ])
 def test_native_ring_with_several_ranks_through_the_loopback_communicator(loopback, world, case, solver, steps, chunks):
     env = dict(os.environ, PICLES_CCL_LIB=str(loopback))
