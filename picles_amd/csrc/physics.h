@@ -178,14 +178,29 @@ PM_HD void dp_load(DPTab &T, int solver)
 }
 #endif
 
-/* tableau access inside the RK loop: on the device every use is an LDS read (ds_read_b64 with a
- * wave-uniform address: the LDS port is otherwise idle, and the 26 live constants would cost 52 VGPRs,
- * the difference between two and three waves per SIMD); on the host a plain struct */
-#if defined(__HIP_DEVICE_COMPILE__)
+/* tableau access inside the RK loop, three forms.  Auto-switching and stand-alone advance kernels: every use is an LDS read
+ * (ds_read_b64 with a wave-uniform address: the LDS port is otherwise idle, and the 26 live constants would cost 52 VGPRs; the
+ * scalar-load form needs a wave-uniform control flow around its pointer barrier, which the solver switch does not offer);
+ * the explicit pairs: scalar loads (below); on the host a plain struct */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PICLES_TABLEAU_SMEM)
+/* the explicit pairs' translation unit (k_step_explicit.hip): every use is a SCALAR load from constant memory, issued stage by
+ * stage behind an opaque copy of the table pointer (TT_STAGE: the loads of a stage cannot be hoisted above it, so at most one
+ * stage's coefficients are live: ~16 SGPRs), and enters the fma as its scalar operand.  No VGPR ever holds a coefficient — with
+ * the LDS form below the constants in flight cost ~30 VGPRs — which is what lets the DP5 / Tsit5 kernels fit 128 registers =
+ * FOUR waves per SIMD (2.40 -> 2.28 ms on the BASELINE box, same instruction count).  As literals (s_mov at the point of use)
+ * the same constants overflowed the scalar file: 44 spilled SGPRs, +40 VALU slots per attempt, +5 %. */
+typedef const __attribute__((opencl_constant)) double *dp_cptr;
+__device__ __forceinline__ dp_cptr dp_launder(dp_cptr p) { __asm__ volatile("" : "+s"(p)); return p; }
+#define DP_TAB_DECL(solver) dp_cptr dp_tab_ = (dp_cptr)&DPTAB_C[(solver)][0]
+#define TT_STAGE() (dp_tab_ = dp_launder(dp_tab_))
+#define TT(f) (dp_tab_[__builtin_offsetof(DPTab, f) / 8])
+#elif defined(__HIP_DEVICE_COMPILE__)
 #define DP_TAB_DECL(solver) const double *const dp_tab_ = dp_lds_tab()
+#define TT_STAGE() ((void)0)
 #define TT(f) (dp_tab_[__builtin_offsetof(DPTab, f) / 8])
 #else
 #define DP_TAB_DECL(solver) DPTab T; dp_load(T, solver)
+#define TT_STAGE() ((void)0)
 #define TT(f) (T.f)
 #endif
 
@@ -737,6 +752,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         /* x,y tendencies are c̄x/Δx, c̄y/Δy of the stage state: their tableau sums run on the stage
          * c̄ itself (Σ a7i c̄_i, Σ e_i c̄_i) and meet the projection 1/Δx, 1/Δy once, at the end */
         double ax, ay, ex, ey;
+        TT_STAGE();
         ax = TT(a71) * z.cx; ay = TT(a71) * z.cy;
         ex = TT(e1) * z.cx; ey = TT(e1) * z.cy;
         double s6x = 0.0, s6y = 0.0;   /* AUTO: Σ a6j c̄_j, the x,y position of stage 6 (stiffness estimate) */
@@ -754,6 +770,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         }
         S6ACC(a62);
 #define ST3(c) PM_FMA(h, PM_FMA(TT(a32), k2.c, TT(a31) * k1.c), z.c)
+        TT_STAGE();
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c3), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k3, pc);
@@ -761,6 +778,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         ex = PM_FMA(TT(e3), gx, ex); ey = PM_FMA(TT(e3), gy, ey);
         S6ACC(a63);
 #define ST4(c) PM_FMA(h, PM_FMA(TT(a43), k3.c, PM_FMA(TT(a42), k2.c, TT(a41) * k1.c)), z.c)
+        TT_STAGE();
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c4), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k4, pc);
@@ -768,6 +786,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         ex = PM_FMA(TT(e4), gx, ex); ey = PM_FMA(TT(e4), gy, ey);
         S6ACC(a64);
 #define ST5(c) PM_FMA(h, PM_FMA(TT(a54), k4.c, PM_FMA(TT(a53), k3.c, PM_FMA(TT(a52), k2.c, TT(a51) * k1.c))), z.c)
+        TT_STAGE();
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
         wind_stage<STATIC>(P, w, PM_FMA(TT(c5), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k5, pc);
@@ -776,6 +795,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         S6ACC(a65);
 #undef S6ACC
 #define ST6(c) PM_FMA(h, PM_FMA(TT(a65), k5.c, PM_FMA(TT(a64), k4.c, PM_FMA(TT(a63), k3.c, PM_FMA(TT(a62), k2.c, TT(a61) * k1.c)))), z.c)
+        TT_STAGE();
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
         wind_stage<STATIC>(P, w, t + h, W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k6, pc);
@@ -783,6 +803,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         ex = PM_FMA(TT(e6), gx, ex); ey = PM_FMA(TT(e6), gy, ey);
 #define S72(c) (has2 ? PM_FMA(TT(a72), k2.c, TT(a71) * k1.c) : TT(a71) * k1.c)
 #define ST7(c) PM_FMA(h, PM_FMA(TT(a76), k6.c, PM_FMA(TT(a75), k5.c, PM_FMA(TT(a74), k4.c, PM_FMA(TT(a73), k3.c, S72(c))))), z.c)
+        TT_STAGE();
         un.lne = ST7(lne); un.cx = ST7(cx); un.cy = ST7(cy);
         un.x = PM_FMA(h, ax * ipx, z.x); un.y = PM_FMA(h, ay * ipy, z.y);
         rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, k7, pc);
@@ -797,6 +818,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             a = un.cy * ipy - gy * ipy; b = un.y - g6y; nu = PM_FMA(a, a, nu); nd = PM_FMA(b, b, nd);
             eig_nu = nu; eig_nd = nd;     /* the test below needs eigen_est² = nu/nd only: no sqrt, no division */
         }
+        TT_STAGE();
         ex = PM_FMA(TT(e7), un.cx, ex) * ipx; ey = PM_FMA(TT(e7), un.cy, ey) * ipy;
 #define E12(c) (has2 ? PM_FMA(TT(e2), k2.c, TT(e1) * k1.c) : TT(e1) * k1.c)
 #define ERRN(c) (h * PM_FMA(TT(e7), k7.c, PM_FMA(TT(e6), k6.c, PM_FMA(TT(e5), k5.c, PM_FMA(TT(e4), k4.c, PM_FMA(TT(e3), k3.c, E12(c)))))))

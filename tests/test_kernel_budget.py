@@ -1,6 +1,7 @@
 """Register / scratch budget of the fused step kernel, from the compiler's own resource report (hipcc cross-compiles gfx950
-without a GPU): the BASELINE flavour `k_step<FAST, DP5, STATIC>` must keep its three waves per SIMD with NO scratch — every
-change of the RHS or of pmath.h that lengthens a live range shows up here before it shows up as time."""
+without a GPU): the BASELINE flavour `k_step<FAST, DP5, STATIC>` must keep its FOUR waves per SIMD (128 VGPRs) with no more than a
+handful of spilled registers — every change of the RHS or of pmath.h that lengthens a live range shows up here before it shows up
+as time."""
 import re
 import shutil
 import subprocess
@@ -13,7 +14,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="no hipcc")
-def test_baseline_kernel_keeps_three_waves_and_no_scratch(tmp_path):
+def test_baseline_kernel_keeps_four_waves_and_its_spill_budget(tmp_path):
     src = ROOT / "picles_amd" / "csrc"
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-munsafe-fp-atomics",
                         "-fPIC", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(src / "k_step_explicit.hip"),
@@ -28,8 +29,8 @@ def test_baseline_kernel_keeps_three_waves_and_no_scratch(tmp_path):
                            vspill=get(r"VGPRs Spill"), sspill=get(r"SGPRs Spill"))
     # template order: k_step<FAST, TSIT, STATIC, METRIC, AUTO>
     base = usage["_Z6k_stepILb1ELb0ELb1ELb0ELb0EEv7KParams5GridP6Arraysddddiiii"]
-    assert base["occ"] == 3 and base["scratch"] == 0 and base["vspill"] == 0 and base["vgpr"] <= 168, base
-    assert base["sspill"] <= 48, base          # scalar spill code is VALU work (v_readlane / v_writelane): 44 -> 55 cost 2.3 % in round 2
+    assert base["occ"] == 4 and base["vgpr"] <= 128 and base["vspill"] <= 10 and base["scratch"] <= 48, base
+    assert base["sspill"] <= 16, base          # scalar spill code is VALU work (v_readlane / v_writelane): 44 -> 55 cost 2.3 % in round 2
     # kargs_reload() (kernels.h) reads the arguments behind the RK loop through a struct that must mirror the kernarg segment:
     # hold its offsets against the compiler's metadata for the kernel (P, G, A, four doubles, four ints)
     asm = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-munsafe-fp-atomics",
@@ -46,7 +47,7 @@ def test_baseline_kernel_keeps_three_waves_and_no_scratch(tmp_path):
         expect.append(pos); pos += size
     assert [a for a, _ in offs] == expect, (offs, expect)
     for name, u in usage.items():
-        if name.startswith("_Z6k_stepILb1E"):          # every specialised-physics flavour runs at three waves per SIMD
-            assert u["occ"] == 3, (name, u)
+        if name.startswith("_Z6k_stepILb1E"):          # every specialised-physics explicit flavour runs at four waves per SIMD
+            assert u["occ"] == 4, (name, u)
         if name.startswith("_Z6k_stepILb1ELb0E"):      # the DP5 flavours (device-sampled winds, per-node metric) stay within a few spilled registers
-            assert u["scratch"] <= 64, (name, u)
+            assert u["scratch"] <= 96, (name, u)
