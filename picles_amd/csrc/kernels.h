@@ -162,17 +162,22 @@ __device__ __forceinline__ int advance_core(const KParams &P, const Wind &w, Vec
     return status;
 }
 
-__device__ __forceinline__ int advance_guards(const KParams &P, const Wind &w, Vec5 &z, double &dtn, double t_start, double DT,
+/* WF: () -> Wind.  k_step hands in a loader instead of the wind itself: the node wind is needed behind the RK loop only by the
+ * (rare) re-seeding guards, and kept in registers across the loop it is what the 128-register build spilled to scratch */
+template <class WF>
+__device__ __forceinline__ int advance_guards(const KParams &P, WF wind, Vec5 &z, double &dtn, double t_start, double DT,
                                               int status, StepStats &S)
 {
     if (pm_isnan(z.lne) || pm_isnan(z.cx) || pm_isnan(z.cy)) {
         double u, v;
+        const Wind w = wind();
         wind_at(P, w, t_start + DT, u, v);
         reseed(P, u, v, DT, z);
         dtn = -1.0;
         status |= PICLES_ST_RESEED_NAN;
     } else if (pm_isinf(z.lne) || pm_isinf(z.cx) || pm_isinf(z.cy)) {
         double u, v;
+        const Wind w = wind();
         wind_at(P, w, t_start, u, v);
         reseed(P, u, v, DT, z);
         dtn = -1.0;
@@ -194,7 +199,7 @@ __device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w,
                                                 double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
 {
     int status = advance_core<FAST, STATIC, METRIC, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, m11, m22, pc, asw);
-    return advance_guards(P, w, z, dtn, t_start, DT, status, S);
+    return advance_guards(P, [&]() { return w; }, z, dtn, t_start, DT, status, S);
 }
 
 /* The kernel arguments of k_step as the kernarg segment lays them out (same order, natural alignment = the C struct rule;
