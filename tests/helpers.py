@@ -53,3 +53,23 @@ def assert_bitwise(a, b, what=""):
         rel = np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
         raise AssertionError(f"{what}: {len(bad)} of {a.size} values differ, first at {k}: "
                              f"{a[k]!r} vs {b[k]!r}; max rel diff {rel:.3e}")
+
+
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def spawn_ranks(fn, args_of_port, nprocs):
+    """torch.multiprocessing.spawn with a rendezvous port picked by the OS.  The port is free when it is picked and can be taken
+    by the time rank 0 listens on it (EADDRINUSE, seen once on a GPU box): that — and only that — is tried again with another port."""
+    import torch.multiprocessing as mp
+    for attempt in range(3):
+        try:
+            return mp.spawn(fn, args=args_of_port(free_port()), nprocs=nprocs, join=True)
+        except Exception as e:  # noqa: BLE001
+            if "EADDRINUSE" in str(e) or "address already in use" in str(e):
+                if attempt < 2:
+                    continue
+            raise

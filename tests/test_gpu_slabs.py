@@ -8,6 +8,8 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+
+from helpers import spawn_ranks
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -58,7 +60,7 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
 def test_gpu_slabs_equal_single_context(tmp_path, name, world, halo):
     from picles_amd.parallel import SlabModel
     n_steps = 4
-    mp.spawn(_worker, args=(world, _free_port(), name, n_steps, halo, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_worker, lambda port: (world, port, name, n_steps, halo, str(tmp_path)), world)
     S = np.load(tmp_path / "state.npy")
     cfg = _cfg(name)
     one = SlabModel(cfg.model, 0, 1, device=0)
@@ -75,7 +77,7 @@ def test_gpu_halo_rows_grow_with_the_reach(tmp_path):
     to 2 cells at step 11 of this box; the run starts with one ghost row and must never overflow"""
     from picles_amd.parallel import SlabModel
     n_steps = 14
-    mp.spawn(_worker, args=(2, _free_port(), "growing_reach", n_steps, 1, str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_worker, lambda port: (2, port, "growing_reach", n_steps, 1, str(tmp_path)), 2)
     S = np.load(tmp_path / "state.npy")
     cfg = _cfg("growing_reach")
     one = SlabModel(cfg.model, 0, 1, device=0)
@@ -164,7 +166,7 @@ def test_rccl_moves_halo_blocks_in_place(tmp_path):
     """the zero-copy mechanics of the multi-GPU path on real hardware: a one-rank RCCL process group sends the edge rows
     of the library's record memory to itself and receives them into the ghost rows (torch.distributed P2P ops on
     __cuda_array_interface__ views, ordered after the advance kernel on the same stream)"""
-    mp.spawn(_nccl_self_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    spawn_ranks(_nccl_self_worker, lambda port: (port, str(tmp_path)), 1)
     ok = np.load(tmp_path / "ok.npy")
     assert ok[0] and ok[1]
 
@@ -193,7 +195,7 @@ def test_ring_of_one_runs_the_multi_gpu_host_loop_over_rccl(tmp_path):
     the pull CONSUMES the rows RCCL delivered in place, ordered behind the edge kernel — and the result must still equal
     the plain single-context run bitwise."""
     from picles_amd.parallel import SlabModel
-    mp.spawn(_ring_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    spawn_ranks(_ring_worker, lambda port: (port, str(tmp_path)), 1)
     S = np.load(tmp_path / "state.npy")
     cfg = _cfg("periodic")
     one = SlabModel(cfg.model, 0, 1, device=0)

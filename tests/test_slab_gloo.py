@@ -9,6 +9,8 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+
+from helpers import spawn_ranks
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -96,8 +98,7 @@ def _single(name, n_steps):
 @pytest.mark.timeout(180)
 def test_slabs_equal_single_domain(tmp_path, name, world, halo):
     n_steps = 4
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, name, n_steps, halo, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_worker, lambda port: (world, port, name, n_steps, halo, str(tmp_path)), world)
     S = np.load(tmp_path / "state.npy")
     ref = _single(name, n_steps)
     assert S.shape == ref.shape
@@ -110,7 +111,7 @@ def test_failed_inplace_exchange_falls_back_to_staging_on_all_ranks(tmp_path):
     refusing the library's memory would do so on every rank), all ranks agree to stage the halo blocks through host
     memory; the run stays bitwise"""
     n_steps = 4
-    mp.spawn(_worker, args=(3, _free_port(), "fallback", n_steps, 1, str(tmp_path)), nprocs=3, join=True)
+    spawn_ranks(_worker, lambda port: (3, port, "fallback", n_steps, 1, str(tmp_path)), 3)
     S = np.load(tmp_path / "state.npy")
     assert np.array_equal(S, _single("fallback", n_steps))
 
@@ -119,7 +120,7 @@ def test_failed_inplace_exchange_falls_back_to_staging_on_all_ranks(tmp_path):
 def test_halo_rows_grow_with_the_reach(tmp_path):
     """auto_halo_every: a run that starts with one ghost row and whose reach passes 2 cells never overflows"""
     n_steps = 14
-    mp.spawn(_worker, args=(2, _free_port(), "growing_reach", n_steps, 1, str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_worker, lambda port: (2, port, "growing_reach", n_steps, 1, str(tmp_path)), 2)
     S = np.load(tmp_path / "state.npy")
     ref = _single("growing_reach", n_steps)
     assert np.array_equal(S, ref), f"max abs diff {np.nanmax(np.abs(S - ref))}"
@@ -151,7 +152,7 @@ def test_unique_id_reaches_every_rank_through_the_store(tmp_path):
     """the one thing torch.distributed does for the native slab ring: rank 0's 128-byte ncclUniqueId reaches all ranks
     through the rendezvous store (no collective)"""
     world = 3
-    mp.spawn(_uid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_uid_worker, lambda port: (world, port, str(tmp_path)), world)
     ref = np.load(tmp_path / "uid0.npy")
     assert ref.size == 3 * 128 and not np.array_equal(ref[:128], ref[128:256])
     for r in range(1, world):
