@@ -319,13 +319,13 @@ def main():
             for winds, solver in (((10.0, 3.0), "DP5"), ((10.0, 3.0), "AutoTsit5"), ((10.0, 10.0), "AutoTsit5")):
                 if tuple(winds) == tuple(args.winds) and solver == args.solver:
                     continue
-                m2, el2 = measure(winds, solver, 0.0, K2, 2)
+                m2, el2 = measure(winds, solver, 0.0, K2, W)          # the same warm-up as the headline: past the ramp-up launches
                 c2 = m2.backend.get_counters()
                 sm = np.sort(m2.backend.get_timing_samples(0))
                 rate = m2.n_stepped * K2 / el2
                 rps = c2["rhs_evals"] / max(m2.n_stepped * K2, 1)
                 tf = c2["rhs_evals"] * FLOP_PER_RHS / el2 / 1e12
-                sec.append({"winds": list(winds), "solver": solver, "steps": K2, "ms_per_step": 1e3 * el2 / K2, "value": rate,
+                sec.append({"winds": list(winds), "solver": solver, "steps": K2, "warmup": W, "ms_per_step": 1e3 * el2 / K2, "value": rate,
                             "rhs_evals_per_particle_step": rps, "fp64_frac": tf / FP64_PEAK_TFLOPS,
                             "hbm_frac": B_ALG * rate / 1e9 / HBM_PEAK_GBPS,
                             "kernel_ms_min_median": [float(sm[0]), float(np.median(sm))] if sm.size else None,
