@@ -783,16 +783,34 @@ static void po_rhs_jvp(const po_model *M, int64_t idx, const double z[5], double
     double ap = (hh * dotc) * sginv2;
     double ya = ap - 0.85;
     double neg2p = -2.0 * k->p;
-    double harg = neg2p * ya;
-    double eH = o_exp((harg > 700.0) ? 700.0 : harg);
-    double hp = 1.0 + eH;
-    double targ = -20.0 * fabs(ya);
-    double t = (targ <= -40.0) ? 0.0 : o_exp(targ);
-    double t1 = 1.0 + t;
-    double t12 = t1 * t1;
-    double rHD = 1.0 / (hp * t12);
-    double H = t12 * rHD;
-    double D = 1.0 - ((5.0 * t) * hp) * rHD;
+    /* H_β, Δ_β and gH = dH/dya = 2p H (1 - H) (physics.h rhs3_jvp) */
+    double hp, t, t1, t12, rHD, H, gH;
+    if (k->p == 0.75) {
+        double w = o_exp(-0.5 * fabs(ya));
+        double w2 = w * w, s3 = w2 * w;
+        double w4 = w2 * w2, w5 = w4 * w, w10 = w5 * w5, w20 = w10 * w10;
+        t = w20 * w20;
+        hp = 1.0 + s3;
+        t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = 1.0 / (hp * t12);
+        H = (t12 * rHD) * ((ya >= 0.0) ? 1.0 : s3);
+        gH = (-neg2p) * (H * (1.0 - H));
+    } else {
+        double harg = neg2p * ya;
+        double eH = o_exp((harg > 700.0) ? 700.0 : harg);
+        hp = 1.0 + eH;
+        double targ = -20.0 * fabs(ya);
+        t = (targ <= -40.0) ? 0.0 : o_exp(targ);
+        t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = 1.0 / (hp * t12);
+        H = t12 * rHD;
+        gH = (harg > 700.0) ? 0.0 : -((H * H) * (eH * neg2p));
+    }
+    double D = PO_FMA(-((5.0 * t) * hp), rHD, 1.0);
+    const double r13 = 1.0 / (t12 * t1);
+    const double rminv = 1.0 / minv;
     double aH = alpha2 * H;
     int n_is_2 = (k->n == 2.0);
     double E2 = o_exp(2.0 * lne);
@@ -827,7 +845,6 @@ static void po_rhs_jvp(const po_model *M, int64_t idx, const double z[5], double
         double drc = -0.5 * ((rc * ic2) * dc2);
         double dminv = (rc <= 10.0) ? drc : 0.0;
         double dwp = (0.5 * G0) * dminv;
-        double dkp = ((0.5 * G0) * minv) * dminv;
         double drc2 = 2.0 * (rc * drc);
         double dU2 = 2.0 * PO_FMA(u, du, v * dv);
         double dqU2 = 0.25 * dU2;
@@ -837,16 +854,16 @@ static void po_rhs_jvp(const po_model *M, int64_t idx, const double z[5], double
         double dcrs = (u * dcy - v * dcx) + (cy * du - cx * dv);
         double dsg = (rc2 <= 1e8) ? drc2 : 0.0;
         double dya = hh * PO_FMA(ddot, sginv2, dotc * dsg);
-        double dhp = (harg > 700.0) ? 0.0 : (eH * neg2p) * dya;
         double sgn = (ya < 0.0) ? 20.0 : -20.0;
         double dt_ = (t * sgn) * dya;
-        double dH = -((H * H) * dhp);
-        double dD = -5.0 * ((dt_ * (1.0 - t)) / (t12 * t1));
+        double dH = gH * dya;
+        double dD = -5.0 * ((dt_ * (1.0 - t)) * r13);
         double daH = PO_FMA(dalpha2, H, alpha2 * dH);
-        double dEk = (ph->dissipation && n_is_2) || ph->peak_shift ? Ek * PO_FMA(2.0, dL, 4.0 * (dkp / kp)) : 0.0;
+        double dlk = dminv * rminv;
+        double dEk = (ph->dissipation && n_is_2) || ph->peak_shift ? Ek * PO_FMA(2.0, dL, 8.0 * dlk) : 0.0;
         double dIt = ph->input ? ph->C_e * daH : 0.0;
         double dDt = (ph->dissipation && n_is_2) ? dEk * ieT4 : 0.0;
-        if (ph->dissipation && !n_is_2) dDt = Dt * PO_FMA(k->n, dL, (2.0 * k->n) * (dkp / kp));
+        if (ph->dissipation && !n_is_2) dDt = Dt * PO_FMA(k->n, dL, (4.0 * k->n) * dlk);
         double dScg = ph->peak_shift ? ph->C_alpha * PO_FMA(dD, Ek, D * dEk) : 0.0;
         double ds2 = 0.0;
         if (!calm && !dead) {

@@ -449,16 +449,35 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     double sginv2 = pm_fmin(rc2, 1e8);
     double ap = (P.half_inv_rg * dotc) * sginv2;
     double ya = ap - 0.85;
-    double harg = P.neg2p * ya;
-    double eH = pm_exp((harg > 700.0) ? 700.0 : harg);
-    double hp = 1.0 + eH;
-    double targ = -20.0 * pm_fabs(ya);
-    double t = (targ <= -40.0) ? 0.0 : pm_exp(targ);
-    double t1 = 1.0 + t;
-    double t12 = t1 * t1;
-    double rHD = pm_rcp_plain(hp * t12);
-    double H = t12 * rHD;
-    double D = 1.0 - ((5.0 * t) * hp) * rHD;
+    /* H_β, Δ_β and the slope gH = dH/dya = 2p H (1 - H) (no e^(-2p ya) needed: H² e^(-2p ya) = H (1 - H)); as in rhs3 one
+     * exponential serves both when 2p = 3/2 */
+    double hp, t, t1, t12, rHD, H, gH;
+    if (FAST || P.p_is_075) {
+        double w = pm_exp(-0.5 * pm_fabs(ya));
+        double w2 = w * w, s3 = w2 * w;
+        double w4 = w2 * w2, w5 = w4 * w, w10 = w5 * w5, w20 = w10 * w10;
+        t = w20 * w20;
+        hp = 1.0 + s3;
+        t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = pm_rcp_plain(hp * t12);
+        H = (t12 * rHD) * ((ya >= 0.0) ? 1.0 : s3);
+        gH = (-P.neg2p) * (H * (1.0 - H));
+    } else {
+        double harg = P.neg2p * ya;
+        double eH = pm_exp((harg > 700.0) ? 700.0 : harg);
+        hp = 1.0 + eH;
+        double targ = -20.0 * pm_fabs(ya);
+        t = (targ <= -40.0) ? 0.0 : pm_exp(targ);
+        t1 = 1.0 + t;
+        t12 = t1 * t1;
+        rHD = pm_rcp_plain(hp * t12);
+        H = t12 * rHD;
+        gH = (harg > 700.0) ? 0.0 : -((H * H) * (eH * P.neg2p));
+    }
+    double D = PM_FMA(-((5.0 * t) * hp), rHD, 1.0);
+    const double r13 = pm_rcp_plain(t12 * t1);       /* (1 + t)³ in [1, 8] */
+    const double rminv = pm_rcp_plain(minv);         /* d k_p / k_p = 2 d(1/c_gp)/(1/c_gp): 1/c_gp in (0, 10] */
     double aH = alpha2 * H;
     const bool n2 = FAST || P.n_is_2;
     const bool s_in = FAST || P.input, s_di = FAST || P.dissipation, s_ps = FAST || P.peak_shift, s_dr = FAST || P.direction;
@@ -485,7 +504,6 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
         double drc = -0.5 * ((rc * ic2) * dc2);
         double dminv = (rc <= 10.0) ? drc : 0.0;
         double dwp = (0.5 * PK_G0) * dminv;
-        double dkp = ((0.5 * PK_G0) * minv) * dminv;
         double drc2 = 2.0 * (rc * drc);
         double dU2 = 2.0 * PM_FMA(u, du, v * dv);
         double dqU2 = 0.25 * dU2;
@@ -495,16 +513,16 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
         double dcrs = (u * dcy - v * dcx) + (cy * du - cx * dv);
         double dsg = (rc2 <= 1e8) ? drc2 : 0.0;
         double dya = P.half_inv_rg * PM_FMA(ddot, sginv2, dotc * dsg);
-        double dhp = (harg > 700.0) ? 0.0 : (eH * P.neg2p) * dya;
         double sgn = (ya < 0.0) ? 20.0 : -20.0;
         double dt_ = (t * sgn) * dya;
-        double dH = -((H * H) * dhp);
-        double dD = -5.0 * ((dt_ * (1.0 - t)) / (t12 * t1));
+        double dH = gH * dya;
+        double dD = -5.0 * ((dt_ * (1.0 - t)) * r13);
         double daH = PM_FMA(dalpha2, H, alpha2 * dH);
-        double dEk = ((s_di && n2) || s_ps) ? Ek * PM_FMA(2.0, dL, 4.0 * (dkp / kp)) : 0.0;
+        double dlk = dminv * rminv;                     /* d k_p / k_p = 2 dlk */
+        double dEk = ((s_di && n2) || s_ps) ? Ek * PM_FMA(2.0, dL, 8.0 * dlk) : 0.0;
         double dIt = s_in ? P.C_e * daH : 0.0;
         double dDt = (s_di && n2) ? dEk * P.inv_eT4 : 0.0;
-        if (s_di && !n2) dDt = Dt * PM_FMA(P.n, dL, (2.0 * P.n) * (dkp / kp));
+        if (s_di && !n2) dDt = Dt * PM_FMA(P.n, dL, (4.0 * P.n) * dlk);
         double dScg = s_ps ? P.C_alpha * PM_FMA(dD, Ek, D * dEk) : 0.0;
         double ds2 = 0.0;
         if (!calm && !dead) {
