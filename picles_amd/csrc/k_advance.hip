@@ -1,5 +1,20 @@
 /* k_advance.hip — the stand-alone advance kernel and its instantiations */
+#define PICLES_TABLEAU_SMEM(FAST, AUTO) ((FAST) && !(AUTO))      /* Butcher tableau through scalar loads in the four-wave flavours (physics.h) */
 #include "kernels.h"
+
+/* the kernel arguments as the kernarg segment lays them out (kargs_reload, kernels.h: behind the RK loop they are read again
+ * instead of living through it in SGPRs) */
+struct KAdvArgs {
+    KParams P;
+    GridP G;
+    Arrays A;
+    double t_start, DT;
+    int r0, n0, r1, n1;
+};
+static_assert(__builtin_offsetof(KAdvArgs, G) == sizeof(KParams) && __builtin_offsetof(KAdvArgs, A) % 8 == 0 &&
+              __builtin_offsetof(KAdvArgs, t_start) == __builtin_offsetof(KAdvArgs, A) + sizeof(Arrays) &&
+              __builtin_offsetof(KAdvArgs, r0) == __builtin_offsetof(KAdvArgs, DT) + 8,
+              "KAdvArgs must mirror the kernarg layout of k_advance");
 
 /* ------------------------------------------------------------------------------------------
  * k_advance — advance! for the particles of the given rows.  One thread per particle; the whole
@@ -7,7 +22,7 @@
  * scattering: the scatter itself is k_scatter / k_step / k_push_tiles.
  * ---------------------------------------------------------------------------------------- */
 template <bool FAST, bool STATIC, bool METRIC, bool TSIT, bool AUTO>
-__global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
+__global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParams P, GridP G, Arrays A, double t_start, double DT,
                                                    int r0, int n0, int r1, int n1)
 {
     dp_device_init(TSIT ? 1 : 0);
@@ -26,15 +41,40 @@ __global__ void __launch_bounds__(256) k_advance(KParams P, GridP G, Arrays A, d
         Wind w = load_wind(P, A, t);
         int status;
         int asw = AUTO ? A.asw[t] : 0;
-        if (METRIC) status = advance_particle<FAST, STATIC, true, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
-        else status = advance_particle<FAST, STATIC, false, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
-        if (AUTO) A.asw[t] = asw;
-        A.z[t] = z.lne; A.z[t + A.n] = z.cx; A.z[t + 2 * A.n] = z.cy; A.z[t + 3 * A.n] = z.x; A.z[t + 4 * A.n] = z.y;
-        A.on[t] = (unsigned char)on;
-        A.qold[t] = qold;
-        A.dtn[t] = dtn;
-        A.status[t] = status;
-        write_record(G, A, i, jl, pf, on, z, S);
+        /* behind the RK loop: guards, particle store, scatter record */
+        auto finish = [&](const KParams &Pq, const GridP &Gq, const Arrays &Aq, long long tq, int iq, int jlq, unsigned char pfq,
+                          double ts, double dt_step, int status) {
+            status = advance_guards(Pq, [&]() { return load_wind(Pq, Aq, tq); }, z, dtn, ts, dt_step, status, S);
+            if (AUTO) Aq.asw[tq] = asw;
+            Aq.z[tq] = z.lne; Aq.z[tq + Aq.n] = z.cx; Aq.z[tq + 2 * Aq.n] = z.cy; Aq.z[tq + 3 * Aq.n] = z.x; Aq.z[tq + 4 * Aq.n] = z.y;
+            Aq.on[tq] = (unsigned char)on;
+            Aq.qold[tq] = qold;
+            Aq.dtn[tq] = dtn;
+            Aq.status[tq] = status;
+            write_record(Gq, Aq, iq, jlq, pfq, on, z, S);
+        };
+        if constexpr (FAST && !AUTO) {
+            /* the four-wave flavours: what is needed again only behind the loop waits in LDS, and the kernel arguments are read
+             * again from the kernarg segment (k_step.inc has the reasons) */
+            __shared__ int stash_[5][256];
+            const int tid_ = threadIdx.x;
+            stash_[0][tid_] = (int)(unsigned int)((unsigned long long)t & 0xffffffffull); stash_[1][tid_] = (int)((unsigned long long)t >> 32);
+            stash_[2][tid_] = i; stash_[3][tid_] = jl; stash_[4][tid_] = (int)pf;
+            if (METRIC) status = advance_core<FAST, STATIC, true, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
+            else status = advance_core<FAST, STATIC, false, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
+            const KAdvArgs *K = (const KAdvArgs *)kargs_reload();
+            const KParams Pb = K->P;
+            const GridP Gb = K->G;
+            const Arrays Ab = K->A;
+            __asm__ volatile("" ::: "memory");
+            const int tid2_ = threadIdx.x;
+            const long long tb = (long long)(((unsigned long long)(unsigned int)stash_[1][tid2_] << 32) | (unsigned int)stash_[0][tid2_]);
+            finish(Pb, Gb, Ab, tb, stash_[2][tid2_], stash_[3][tid2_], (unsigned char)(stash_[4][tid2_] & 0xff), K->t_start, K->DT, status);
+        } else {
+            if (METRIC) status = advance_core<FAST, STATIC, true, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
+            else status = advance_core<FAST, STATIC, false, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
+            finish(P, G, A, t, i, jl, pf, t_start, DT, status);
+        }
     }
     flush_stats(A, S);
 }

@@ -220,7 +220,7 @@ static_assert(__builtin_offsetof(KStepArgs, G) == sizeof(KParams) && __builtin_o
               __builtin_offsetof(KStepArgs, r0) == __builtin_offsetof(KStepArgs, DT) + 8,
               "KStepArgs must mirror the kernarg layout of k_step");
 typedef const KStepArgs *KStepArgsPtr;
-__device__ __forceinline__ KStepArgsPtr kargs_reload(void)
+__device__ __forceinline__ KStepArgsPtr kargs_reload(void)      /* k_advance casts the result to its own argument struct */
 {
     auto p = __builtin_amdgcn_kernarg_segment_ptr();      /* constant address space */
     __asm__ volatile("" : "+s"(p));      /* a pointer the compiler knows nothing about: no load through it moves above this line */

@@ -181,24 +181,27 @@ PM_HD void dp_load(DPTab &T, int solver)
 /* tableau access inside the RK loop, three forms.  The stand-alone advance kernel: every use is an LDS read (ds_read_b64 with a
  * wave-uniform address: the LDS port is otherwise idle, and the 26 live constants would cost 52 VGPRs); the fused step kernels
  * (k_step_explicit.hip, k_step_auto.hip): scalar loads (below); on the host a plain struct */
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PICLES_TABLEAU_SMEM)
-/* the fused step kernels: every use is a SCALAR load from constant memory, issued stage by
- * stage behind an opaque copy of the table pointer (TT_STAGE: the loads of a stage cannot be hoisted above it, so at most one
- * stage's coefficients are live: ~16 SGPRs), and enters the fma as its scalar operand.  No VGPR ever holds a coefficient — with
- * the LDS form below the constants in flight cost ~30 VGPRs — which is what lets the DP5 / Tsit5 kernels fit 128 registers =
- * FOUR waves per SIMD (2.40 -> 2.28 ms on the BASELINE box, same instruction count).  As literals (s_mov at the point of use)
- * the same constants overflowed the scalar file: 44 spilled SGPRs, +40 VALU slots per attempt, +5 %. */
+#if defined(__HIP_DEVICE_COMPILE__)
+/* PICLES_TABLEAU_SMEM(FAST, AUTO): which instantiations of a translation unit take the scalar-load form (default: none).
+ * Scalar-load form: every use is a SCALAR load from constant memory, issued stage by stage behind an opaque copy of the table
+ * pointer (TT_STAGE: the loads of a stage cannot be hoisted above it, so at most one stage's coefficients are live: ~16 SGPRs), and
+ * enters the fma as its scalar operand.  No VGPR ever holds a coefficient — with the LDS form the constants in flight cost ~30
+ * VGPRs — which is what lets the DP5 / Tsit5 kernels fit 128 registers = FOUR waves per SIMD (2.40 -> 2.28 ms on the BASELINE box,
+ * same instruction count).  As literals (s_mov at the point of use) the same constants overflowed the scalar file: 44 spilled
+ * SGPRs, +40 VALU slots per attempt, +5 %.  Every barrier starts from the table's address again, not from the previous copy: no
+ * value is carried across the (divergent) branches of the auto-switching kernel, whose merge would otherwise turn the pointer into
+ * a per-lane value.  The form needs scalar registers to spare: the general-physics and auto-switching flavours of the stand-alone
+ * advance kernel, which keep all their arguments live, stay with LDS. */
+#ifndef PICLES_TABLEAU_SMEM
+#define PICLES_TABLEAU_SMEM(FAST, AUTO) false
+#endif
 typedef const __attribute__((opencl_constant)) double *dp_cptr;
 __device__ __forceinline__ dp_cptr dp_launder(dp_cptr p) { __asm__ volatile("" : "+s"(p)); return p; }
-#define DP_TAB_DECL(solver) constexpr int dp_solver_ = (solver); dp_cptr dp_tab_ = (dp_cptr)&DPTAB_C[dp_solver_][0]
-/* every barrier starts from the table's address again, not from the previous copy: no value is carried across the (divergent)
- * branches of the auto-switching kernel, whose merge would otherwise turn the pointer into a per-lane value */
-#define TT_STAGE() (dp_tab_ = dp_launder((dp_cptr)&DPTAB_C[dp_solver_][0]))
-#define TT(f) (dp_tab_[__builtin_offsetof(DPTab, f) / 8])
-#elif defined(__HIP_DEVICE_COMPILE__)
-#define DP_TAB_DECL(solver) const double *const dp_tab_ = dp_lds_tab()
-#define TT_STAGE() ((void)0)
-#define TT(f) (dp_tab_[__builtin_offsetof(DPTab, f) / 8])
+#define DP_TAB_DECL(solver)                                                                                      \
+    constexpr int dp_solver_ = (solver); constexpr bool dp_smem_ = PICLES_TABLEAU_SMEM(FAST, AUTO);              \
+    dp_cptr dp_ctab_ = (dp_cptr)&DPTAB_C[dp_solver_][0]; const double *const dp_ltab_ = dp_lds_tab()
+#define TT_STAGE() do { if constexpr (dp_smem_) dp_ctab_ = dp_launder((dp_cptr)&DPTAB_C[dp_solver_][0]); } while (0)
+#define TT(f) (dp_smem_ ? dp_ctab_[__builtin_offsetof(DPTab, f) / 8] : dp_ltab_[__builtin_offsetof(DPTab, f) / 8])
 #else
 #define DP_TAB_DECL(solver) DPTab T; dp_load(T, solver)
 #define TT_STAGE() ((void)0)
