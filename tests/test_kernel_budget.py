@@ -51,3 +51,25 @@ def test_baseline_kernel_keeps_four_waves_and_its_spill_budget(tmp_path):
             assert u["occ"] == 4, (name, u)
         if name.startswith("_Z6k_stepILb1ELb0E"):      # the DP5 flavours (device-sampled winds, per-node metric) stay within a few spilled registers
             assert u["scratch"] <= 96, (name, u)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="no hipcc")
+def test_advance_kernel_argument_struct_mirrors_the_kernarg_segment():
+    """k_advance's four-wave flavours re-read their arguments behind the RK loop through `KAdvArgs` (k_advance.hip): its layout — the C
+    struct rule over (KParams, GridP, Arrays, two doubles, four ints) — against the compiler's metadata for the kernel"""
+    src = ROOT / "picles_amd" / "csrc"
+    asm = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-munsafe-fp-atomics",
+                          "-fPIC", "--cuda-device-only", "-S", str(src / "k_advance.hip"), "-o", "-"], capture_output=True, text=True,
+                         cwd=src, timeout=900).stdout
+    meta = asm[asm.find("amdhsa.kernels"):]
+    name = "_Z9k_advanceILb1ELb1ELb0ELb0ELb0EEv7KParams5GridP6Arraysddiiii"
+    assert name in meta
+    entry = meta[:meta.find(name)]
+    offs = [(int(a), int(b)) for a, b in re.findall(r"\.offset:\s+(\d+)\s*\n\s*\.size:\s+(\d+)", entry[entry.rfind(".args:"):])][:9]
+    sizes = [b for _, b in offs]
+    assert sizes[3:] == [8, 8, 4, 4, 4, 4], offs
+    expect, pos = [], 0
+    for size, align in [(sizes[0], 8), (sizes[1], 4), (sizes[2], 8)] + [(8, 8)] * 2 + [(4, 4)] * 4:
+        pos = (pos + align - 1) // align * align
+        expect.append(pos); pos += size
+    assert [a for a, _ in offs] == expect, (offs, expect)
