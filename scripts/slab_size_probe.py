@@ -20,5 +20,5 @@ for ny in (4096, 2048, 1024, 512):
     dt = (time.perf_counter() - t0) / 30
     tim = m.backend.get_timing()
     print(f"4096 x {ny}: {1e3*dt:.3f} ms/step wall, kernel {tim['advance_ms']/max(tim['advance_launches'],1):.3f} ms, "
-          f"{4096*ny/dt:.3e} particle-steps/s, ideal from 4096²: {2.70*ny/4096:.3f} ms")
+          f"{4096*ny/dt:.3e} particle-steps/s, linear from 4096² (2.34 ms): {2.34*ny/4096:.3f} ms")
     del m
