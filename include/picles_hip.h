@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PICLES_ABI_VERSION 2
+#define PICLES_ABI_VERSION 3
 
 /* ---- grid: TwoDCartesianGridStatistics + mesh mask (Grids/CartesianGrid.jl:26-101,
  *      Grids/mask_utils.jl:38-55) ------------------------------------------------ */
@@ -114,6 +114,9 @@ typedef struct picles_counters {
     int32_t  max_reach_seen;  /* the largest max_reach since picles_seed / picles_reset_counters (slab halos are sized from it) */
     uint64_t dropped_nonfinite; /* switched-on particles whose advanced position was NaN / Inf: not scattered.  The reference
                                  would throw in Int(floor(NaN)) (ParticleInCell.jl:58-71); here they are dropped and counted */
+    uint64_t wave_attempt_slots; /* sum over wavefronts of 64 x (the largest number of internal RK attempts any lane of the wave
+                                 made): (steps_accepted + steps_rejected) / wave_attempt_slots is the lane efficiency of the
+                                 adaptive advance — 1 when all particles of a wave take the same number of attempts */
 } picles_counters;
 
 typedef struct picles_timing {     /* accumulated device time, ms (HIP events on the compute stream) */
@@ -138,6 +141,13 @@ int32_t picles_abi_version(void);
  * Replaces the Julia closures winds.u(x,y,t) (particle_waves_v5.jl:494-495). */
 int32_t picles_set_winds(picles_ctx *ctx, const double *u0, const double *v0, double t0,
                          const double *u1, const double *v1, double t1);
+/* The same with a third level (um, vm) at the middle of the window, (t0 + t1)/2: the RHS evaluates the parabola through the
+ * three levels.  For closures that are not linear in t inside a model step (tests/T04_2D_reg_test.jl:166-167 multiplies u by
+ * cos(3t/(3600 2π))) the two-level form misses the reference's u_wind(x,y,t) at the stage times (particle_waves_v5.jl:494-495)
+ * by (ω Δt)²/8 of the amplitude, this one by (ω Δt)³/125.  um == NULL is picles_set_winds. */
+int32_t picles_set_winds3(picles_ctx *ctx, const double *u0, const double *v0, double t0,
+                          const double *um, const double *vm,
+                          const double *u1, const double *v1, double t1);
 
 /* Non-Cartesian meshes (SphericalGrid.jl:207-240, spherical_grid_corrections.jl:3-21): per-node
  * projection kernel M = diag(m11, m22) of the propagation terms (particle_waves_v5.jl:536) and the
@@ -156,6 +166,8 @@ int32_t picles_set_wind_grid(picles_ctx *ctx, int32_t nx, int32_t ny, int32_t nt
                              const double *u, const double *v, double mesh_x0, double mesh_y0);
 /* node winds currently on the device (own rows); any pointer may be NULL */
 int32_t picles_get_winds(picles_ctx *ctx, double *u0, double *v0, double *u1, double *v1);
+/* the mid-window level of three-level winds; returns 1 (and writes nothing) when the current winds have two levels */
+int32_t picles_get_winds_mid(picles_ctx *ctx, double *um, double *vm);
 
 /* init_particles!(model) + SeedParticle (run.jl:199-247, core_2D.jl:434-488); clock := t0 */
 int32_t picles_seed(picles_ctx *ctx, double t0);

@@ -131,6 +131,7 @@ typedef struct po_model {
     int64_t n_step;
     int64_t *steplist;         /* ocean_points in reference order */
     double *u0, *v0, *u1, *v1;
+    double *um, *vm;           /* mid-window level of three-level winds (picles_oracle_set_winds3); NULL: two levels */
     double *m11, *m22, *pc;    /* per-node projection M = diag(m11, m22) and great-circle coefficient (NULL: Cartesian) */
     double tw0, tw1;
     int wind_static;
@@ -412,7 +413,9 @@ static inline void po_rhs(const po_model *M, int64_t idx, const double z[5], dou
 }
 
 /* node wind at absolute time t: the boundary's replacement of the closures u(x,y,t), v(x,y,t)
- * (particle_waves_v5.jl:494-495): linear in t between two node-sampled levels. */
+ * (particle_waves_v5.jl:494-495): the interpolant through the node-sampled levels of the step window — two levels: linear in t;
+ * three levels (t0, (t0+t1)/2, t1): the parabola.  Order 0 writes the Lagrange form, order 1 the kernels' Newton form
+ * u0 + s (du + (s - 1) bu), bu = 2 ((u0 + u1) - 2 um) (physics.h, Wind). */
 static inline void po_wind(const po_model *M, int64_t idx, double t, double *u, double *v)
 {
     if (M->wind_static) {
@@ -422,12 +425,24 @@ static inline void po_wind(const po_model *M, int64_t idx, double t, double *u, 
     }
     if (M->order == 0) {
         double s = (t - M->tw0) / (M->tw1 - M->tw0);
-        *u = M->u0[idx] + (M->u1[idx] - M->u0[idx]) * s;
-        *v = M->v0[idx] + (M->v1[idx] - M->v0[idx]) * s;
+        if (M->um) {
+            double l0 = (2.0 * s - 1.0) * (s - 1.0), lm = 4.0 * s * (1.0 - s), l1 = s * (2.0 * s - 1.0);
+            *u = M->u0[idx] * l0 + M->um[idx] * lm + M->u1[idx] * l1;
+            *v = M->v0[idx] * l0 + M->vm[idx] * lm + M->v1[idx] * l1;
+        } else {
+            *u = M->u0[idx] + (M->u1[idx] - M->u0[idx]) * s;
+            *v = M->v0[idx] + (M->v1[idx] - M->v0[idx]) * s;
+        }
     } else {
         double s = (t - M->tw0) * (1.0 / (M->tw1 - M->tw0));
-        *u = PO_FMA(M->u1[idx] - M->u0[idx], s, M->u0[idx]);
-        *v = PO_FMA(M->v1[idx] - M->v0[idx], s, M->v0[idx]);
+        double s1 = s - 1.0;
+        double bu = 0.0, bv = 0.0;
+        if (M->um) {
+            bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
+            bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
+        }
+        *u = PO_FMA(PO_FMA(bu, s1, M->u1[idx] - M->u0[idx]), s, M->u0[idx]);
+        *v = PO_FMA(PO_FMA(bv, s1, M->v1[idx] - M->v0[idx]), s, M->v0[idx]);
     }
 }
 
@@ -891,10 +906,16 @@ static double po_ros23_try(const po_model *M, int64_t idx, const double u0[5], c
     double uw, vw, uw1, vw1;
     po_wind(M, idx, t, &uw, &vw);
     double dudt = 0.0, dvdt = 0.0;
-    if (!M->wind_static) {
+    if (!M->wind_static) {      /* d/dt of the window's interpolant at t: (du + (2 s - 1) bu) / (tw1 - tw0) */
         double idt = 1.0 / (M->tw1 - M->tw0);
-        dudt = (M->u1[idx] - M->u0[idx]) * idt;
-        dvdt = (M->v1[idx] - M->v0[idx]) * idt;
+        double s21 = PO_FMA(2.0, (t - M->tw0) * idt, -1.0);
+        double bu = 0.0, bv = 0.0;
+        if (M->um) {
+            bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
+            bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
+        }
+        dudt = PO_FMA(bu, s21, M->u1[idx] - M->u0[idx]) * idt;
+        dvdt = PO_FMA(bv, s21, M->v1[idx] - M->v0[idx]) * idt;
     }
     const double seeds[4][5] = {{1, 0, 0, 0, 0}, {0, 1, 0, 0, 0}, {0, 0, 1, 0, 0}, {0, 0, 0, dudt, dvdt}};
     double fj[3], dfs[4][3] = {{0}};
@@ -1338,7 +1359,7 @@ PO_EXPORT int32_t picles_oracle_destroy(po_model *M)
     if (!M) return 0;
     free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->asw); free(M->dtn); free(M->grp); free(M->rec);
     free(M->on); free(M->bnd); free(M->status); free(M->steplist);
-    free(M->u0); free(M->v0); free(M->u1); free(M->v1);
+    free(M->u0); free(M->v0); free(M->u1); free(M->v1); free(M->um); free(M->vm);
     free(M->m11); free(M->m22); free(M->pc);
     free(M);
     return 0;
@@ -1360,22 +1381,34 @@ PO_EXPORT int32_t picles_oracle_set_metric(po_model *M, const double *m11, const
 
 PO_EXPORT int32_t picles_oracle_set_threads(po_model *M, int32_t n) { M->nthreads = n > 0 ? n : 1; return 0; }
 
-PO_EXPORT int32_t picles_oracle_set_winds(po_model *M, const double *u0, const double *v0, double t0,
-                                          const double *u1, const double *v1, double t1)
+PO_EXPORT int32_t picles_oracle_set_winds3(po_model *M, const double *u0, const double *v0, double t0,
+                                           const double *um, const double *vm,
+                                           const double *u1, const double *v1, double t1)
 {
     memcpy(M->u0, u0, M->N * 8);
     memcpy(M->v0, v0, M->N * 8);
     M->tw0 = t0;
+    free(M->um); free(M->vm);
+    M->um = M->vm = NULL;
     if (u1 && v1 && t1 != t0) {
         memcpy(M->u1, u1, M->N * 8);
         memcpy(M->v1, v1, M->N * 8);
         M->tw1 = t1;
         M->wind_static = 0;
+        if (um && vm) {
+            M->um = (double *)malloc(M->N * 8); memcpy(M->um, um, M->N * 8);
+            M->vm = (double *)malloc(M->N * 8); memcpy(M->vm, vm, M->N * 8);
+        }
     } else {
         M->wind_static = 1;
         M->tw1 = t0;
     }
     return 0;
+}
+PO_EXPORT int32_t picles_oracle_set_winds(po_model *M, const double *u0, const double *v0, double t0,
+                                          const double *u1, const double *v1, double t1)
+{
+    return picles_oracle_set_winds3(M, u0, v0, t0, NULL, NULL, u1, v1, t1);
 }
 
 /* init_particles! (run.jl:199-247) -> SeedParticle (core_2D.jl:434-488) -> InitParticleValues

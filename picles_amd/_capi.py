@@ -67,7 +67,7 @@ class PiclesCounters(C.Structure):
         ("reseeds", C.c_uint64), ("clamps", C.c_uint64), ("maxiters_hits", C.c_uint64),
         ("particles_advanced", C.c_uint64), ("halo_overflow", C.c_uint64),
         ("max_reach", C.c_int32), ("max_reach_seen", C.c_int32),
-        ("dropped_nonfinite", C.c_uint64),
+        ("dropped_nonfinite", C.c_uint64), ("wave_attempt_slots", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -89,7 +89,7 @@ class PiclesTiming(C.Structure):
 STEP_ZERO_FIRST = 1
 STEP_MOVIE = 2
 STEP_ATOMIC = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 SLAB_ID_BYTES = 128
 
 ROWS_ALL, ROWS_EDGE, ROWS_INTERIOR = 0, 1, 2
@@ -106,6 +106,8 @@ SYMBOLS = {
     "picles_last_error": (C.c_char_p, [_VP]),
     "picles_abi_version": (C.c_int32, []),
     "picles_set_winds": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, C.c_double]),
+    "picles_set_winds3": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double]),
+    "picles_get_winds_mid": (C.c_int32, [_VP, c_double_p, c_double_p]),
     "picles_set_metric": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p]),
     "picles_set_wind_grid": (C.c_int32, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                          C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, C.c_double, C.c_double]),

@@ -35,7 +35,7 @@ struct GridP {
 #define NSLOTS 1024
 struct DevCounters {
     unsigned long long rhs, acc, rej, reseeds, clamps, maxit, adv, overflow;
-    unsigned long long nonfinite, pad_[7];     /* two 64-B lines per slot */
+    unsigned long long nonfinite, wslots, pad_[6];     /* two 64-B lines per slot; wslots: 64 x the wave's largest attempt count */
 };
 
 struct Arrays {
@@ -46,6 +46,7 @@ struct Arrays {
     unsigned char *on, *pflags;
     int *status;
     double *u0, *v0, *u1, *v1;
+    double *um, *vm;         /* mid-window level of three-level winds (picles_set_winds3); NULL: two levels, linear in t */
     double *uP, *vP;         /* level-0 winds of the previous step's window (fused steps under time-varying winds) */
     double *m11, *m22, *pc;  /* per-node projection diag and great-circle coefficient (NULL: Cartesian) */
     double *rec;             /* records the scatter reads  (latest completed advance) */
@@ -87,12 +88,19 @@ __device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, lon
     Wind w;
     w.u0 = A.u0[t];
     w.v0 = A.v0[t];
+    w.bu = 0.0;
+    w.bv = 0.0;
     if (P.wind_static) {
         w.du = 0.0;
         w.dv = 0.0;
     } else {
-        w.du = A.u1[t] - w.u0;
-        w.dv = A.v1[t] - w.v0;
+        const double u1 = A.u1[t], v1 = A.v1[t];
+        w.du = u1 - w.u0;
+        w.dv = v1 - w.v0;
+        if (A.um) {      /* three levels: curvature term of the parabola through them (physics.h, Wind) */
+            w.bu = 2.0 * ((w.u0 + u1) - 2.0 * A.um[t]);
+            w.bv = 2.0 * ((w.v0 + v1) - 2.0 * A.vm[t]);
+        }
     }
     return w;
 }
@@ -267,6 +275,7 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
     unsigned long long b_adv = __ballot(S.adv != 0), b_res1 = __ballot(S.reseeds == 1), b_res2 = __ballot(S.reseeds >= 2);
     unsigned long long b_cl = __ballot(S.clamps != 0), b_mx = __ballot(S.maxit != 0), b_ov = __ballot(S.overflow != 0);
     unsigned long long b_nf = __ballot(S.nonfinite != 0);
+    const int m_att = wave_max_i32((int)(S.st.acc + S.st.rej));        /* the attempts this wave ran: its slowest lane's */
     int m_reach = 0;
     if (__ballot(S.reach > 0)) {
         m_reach = 1;
@@ -285,6 +294,7 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
         if (b_mx) atomicAdd(&c->maxit, (unsigned long long)__popcll(b_mx));
         if (b_ov) atomicAdd(&c->overflow, (unsigned long long)__popcll(b_ov));
         if (b_nf) atomicAdd(&c->nonfinite, (unsigned long long)__popcll(b_nf));
+        if (m_att) atomicAdd(&c->wslots, 64ull * (unsigned long long)m_att);
         /* one address for the whole grid: only waves that would raise it touch it */
         int *const mr = reach_counters(A), *const mr_out = mr + ((A.mr_idx >> 4) & 15);
         if (m_reach > __hip_atomic_load(mr_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {

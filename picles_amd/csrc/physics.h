@@ -212,8 +212,15 @@ struct Vec5 {
     double lne, cx, cy, x, y;
 };
 
+/* node wind over the step window [tw0, tw1], s = (t - tw0)/(tw1 - tw0):  u(s) = u0 + s (du + (s - 1) bu)  — the parabola through
+ * the three levels u0 = u(tw0), um = u((tw0+tw1)/2), u1 = u(tw1) in Newton form, du = u1 - u0, bu = 2 ((u0 + u1) - 2 um).
+ * Two-level winds (picles_set_winds, the device-sampled lattice) have bu = bv = 0 and are the straight line, bit for bit what
+ * the two-level code computed: fma(0, s - 1, du) = du.  The reference calls the closures u(x,y,t), v(x,y,t) at every stage time
+ * (particle_waves_v5.jl:494-495); for a forcing of angular frequency ω the line misses it by (ω Δt)²/8 of its amplitude at
+ * mid-step, the parabola by (ω Δt)³/125 (T04_2D_reg_test.jl:167 with Δt = 20 min: 3.2e-3 against 3.2e-5). */
 struct Wind {
     double u0, v0, du, dv; /* level 0 and (level1 - level0) */
+    double bu, bv;         /* curvature term of the three-level window (0: linear in t) */
 };
 
 struct PStats {
@@ -236,6 +243,24 @@ PM_HD void wind_derive(const KParams &P, double u, double v, WindD &d)
     d.qU2 = 0.25 * d.U2;
     d.sK = P.Cdir * d.invU2;
 }
+/* the same for the stage winds of a time-varying window (seven times per RK attempt): 1/U² through the plain-range reciprocal
+ * — the bits of the division for a normal operand far from the ends of the exponent range, 7 issue slots instead of the IEEE
+ * expansion's 11 — behind a wave-uniform range test; a calm (U² = 0), subnormal or non-finite lane sends the wave through the
+ * division itself */
+PM_HD void wind_derive_stage(const KParams &P, double u, double v, WindD &d)
+{
+    d.u = u;
+    d.v = v;
+    d.U2 = PM_FMA(u, u, v * v);
+    if (PM_WAVE_ALL(d.U2 >= 1e-290 && d.U2 <= 1e290)) {
+        d.invU2 = pm_rcp_plain(d.U2);
+    } else {
+        PM_RARE_PATH();
+        d.invU2 = 1.0 / d.U2;
+    }
+    d.qU2 = 0.25 * d.U2;
+    d.sK = P.Cdir * d.invU2;
+}
 PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double &v)
 {
     if (P.wind_static) {
@@ -243,8 +268,9 @@ PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double 
         v = w.v0;
     } else {
         double s = (t - P.tw0) * P.inv_dtw;
-        u = PM_FMA(w.du, s, w.u0);
-        v = PM_FMA(w.dv, s, w.v0);
+        double s1 = s - 1.0;
+        u = PM_FMA(PM_FMA(w.bu, s1, w.du), s, w.u0);
+        v = PM_FMA(PM_FMA(w.bv, s1, w.dv), s, w.v0);
     }
 }
 template <bool STATIC>
@@ -252,7 +278,8 @@ PM_HD void wind_stage(const KParams &P, const Wind &w, double t, WindD &d)
 {
     if (!STATIC) {
         double s = (t - P.tw0) * P.inv_dtw;
-        wind_derive(P, PM_FMA(w.du, s, w.u0), PM_FMA(w.dv, s, w.v0), d);
+        double s1 = s - 1.0;
+        wind_derive_stage(P, PM_FMA(PM_FMA(w.bu, s1, w.du), s, w.u0), PM_FMA(PM_FMA(w.bv, s1, w.dv), s, w.v0), d);
     }
 }
 
@@ -554,7 +581,10 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     seeds[0] = {1.0, 0.0, 0.0, 0.0, 0.0};
     seeds[1] = {0.0, 1.0, 0.0, 0.0, 0.0};
     seeds[2] = {0.0, 0.0, 1.0, 0.0, 0.0};
-    if (!STATIC) seeds[NS - 1] = {0.0, 0.0, 0.0, w.du * P.inv_dtw, w.dv * P.inv_dtw};
+    if (!STATIC) {      /* du/dt, dv/dt of the window's parabola at t: (du + (2 s - 1) bu) / (tw1 - tw0) */
+        const double s21 = PM_FMA(2.0, (t - P.tw0) * P.inv_dtw, -1.0);
+        seeds[NS - 1] = {0.0, 0.0, 0.0, PM_FMA(w.bu, s21, w.du) * P.inv_dtw, PM_FMA(w.bv, s21, w.dv) * P.inv_dtw};
+    }
     const bool tv = !STATIC && !P.wind_static;   /* a time-varying instantiation may run with static winds: no dT terms then */
     wind_stage<STATIC>(P, w, t, W);
     rhs3_jvp<FAST, METRIC, NS>(P, z.lne, z.cx, z.cy, W, pc, seeds, dfs);

@@ -440,6 +440,7 @@ struct picles_ctx {
     double *d_wgu = nullptr, *d_wgv = nullptr;
     double wind_t1 = 0.0;          /* time level currently held in (u1, v1) */
     bool wind_t1_valid = false;
+    double *um_buf = nullptr, *vm_buf = nullptr;   /* mid-window wind level (picles_set_winds3); A.um / A.vm point here while in use */
     bool ext_streams = false;      /* a caller-provided stream has been used: order across streams with device syncs */
     bool ring_orders = false;      /* inside picles_slab_run_steps: the ring orders its streams against the context stream with events */
     /* generic scatter scratch */
@@ -524,8 +525,8 @@ static int launch_scatter(picles_ctx *c, hipStream_t s, bool remesh);
 static int flush(picles_ctx *c)
 {
     if (!c->pending) return 0;
-    c->pending = false;
     HIPCHK(c, hipDeviceSynchronize());   /* the fused launches may have run on caller-provided streams */
+    c->pending = false;                  /* only now: a failed synchronisation leaves the step pending */
     double clock_save = c->clock, dt_save = c->step_dt;
     int flags_save = c->step_flags;
     c->clock = c->pend_t;           /* remesh samples the wind at the start-of-step clock */
@@ -706,6 +707,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipFree(A.state); hipFree(A.movie); hipFree(A.z); hipFree(A.qold); hipFree(A.dtn); hipFree(A.asw); hipFree(A.on);
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
+    if (c->um_buf) { hipFree(c->um_buf); hipFree(c->vm_buf); }
     hipFree(A.cnt); hipFree(c->d_mask);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
     for (int k = 0; k < 2; k++) hipFree(c->rec_buf[k]);
@@ -741,20 +743,23 @@ PX_EXPORT int32_t picles_sync(picles_ctx *c)
 
 PX_EXPORT double picles_clock(const picles_ctx *c) { return c ? c->clock : 0.0; }
 
-PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double *v0, double t0,
-                                   const double *u1, const double *v1, double t1)
+PX_EXPORT int32_t picles_set_winds3(picles_ctx *c, const double *u0, const double *v0, double t0,
+                                    const double *um, const double *vm,
+                                    const double *u1, const double *v1, double t1)
 {
     if (!c || !u0 || !v0) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());   /* the previous step may still read the wind planes */
     c->wind_grid_on = false;
-    size_t b = (size_t)c->A.n * 8;
-    HIPCHK(c, hipMemcpyAsync(c->A.u0, u0, b, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->A.v0, v0, b, hipMemcpyHostToDevice, c->stream));
-    if (u1 && v1 && t1 != t0) {
-        HIPCHK(c, hipMemcpyAsync(c->A.u1, u1, b, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->A.v1, v1, b, hipMemcpyHostToDevice, c->stream));
+    Arrays &A = c->A;
+    size_t b = (size_t)A.n * 8;
+    HIPCHK(c, hipMemcpyAsync(A.u0, u0, b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(A.v0, v0, b, hipMemcpyHostToDevice, c->stream));
+    const bool two = u1 && v1 && t1 != t0;
+    if (two) {
+        HIPCHK(c, hipMemcpyAsync(A.u1, u1, b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(A.v1, v1, b, hipMemcpyHostToDevice, c->stream));
         c->P.wind_static = 0;
         c->P.tw0 = t0;
         c->P.inv_dtw = 1.0 / (t1 - t0);
@@ -763,8 +768,25 @@ PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double
         c->P.tw0 = t0;
         c->P.inv_dtw = 0.0;
     }
+    if (two && um && vm) {               /* third level: the planes exist from the first three-level call on */
+        if (!c->um_buf) {
+            HIPCHK(c, hipMalloc(&c->um_buf, b));
+            HIPCHK(c, hipMalloc(&c->vm_buf, b));
+        }
+        HIPCHK(c, hipMemcpyAsync(c->um_buf, um, b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->vm_buf, vm, b, hipMemcpyHostToDevice, c->stream));
+        A.um = c->um_buf; A.vm = c->vm_buf;
+    } else {
+        A.um = A.vm = nullptr;           /* two levels: linear in t (bit for bit the two-level arithmetic) */
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));   /* caller may reuse its host buffers */
     return 0;
+}
+
+PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double *v0, double t0,
+                                   const double *u1, const double *v1, double t1)
+{
+    return picles_set_winds3(c, u0, v0, t0, nullptr, nullptr, u1, v1, t1);
 }
 
 static inline unsigned nblocks(long long n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -807,6 +829,7 @@ PX_EXPORT int32_t picles_set_wind_grid(picles_ctx *c, int32_t nx, int32_t ny, in
     w.x0 = x0; w.inv_dx = 1.0 / dx; w.y0 = y0; w.inv_dy = 1.0 / dy; w.t0 = t0; w.inv_dt = 1.0 / dt;
     w.mesh_x0 = mesh_x0; w.mesh_y0 = mesh_y0; w.mesh_dx = c->g.dx; w.mesh_dy = c->g.dy;
     w.u = c->d_wgu; w.v = c->d_wgv;
+    c->A.um = c->A.vm = nullptr;         /* the lattice is linear in t between its knots: two levels per window */
     c->wind_grid_on = true;
     c->wind_t1_valid = false;
     return 0;
@@ -847,10 +870,23 @@ PX_EXPORT int32_t picles_get_winds(picles_ctx *c, double *u0, double *v0, double
     return 0;
 }
 
+PX_EXPORT int32_t picles_get_winds_mid(picles_ctx *c, double *um, double *vm)
+{
+    if (!c) return -1;
+    if (!c->A.um) return 1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    size_t b = (size_t)c->A.n * 8;
+    if (um) HIPCHK(c, hipMemcpy(um, c->A.um, b, hipMemcpyDeviceToHost));
+    if (vm) HIPCHK(c, hipMemcpy(vm, c->A.vm, b, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
 {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->ext_streams) HIPCHK(c, hipDeviceSynchronize());   /* earlier steps may still run on caller / ring streams */
     c->clock = t0;
     if (c->wind_grid_on) {   /* winds at t = 0.0 seed the particles (run.jl:213-215) */
         c->wind_t1_valid = false;
@@ -879,6 +915,8 @@ PX_EXPORT int32_t picles_zero_state(picles_ctx *c)
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     { int rc = flush(c); if (rc) return rc; }
+    /* launches on caller / ring streams (the un-fused slab phases: k_scatter on stream M) may still be writing State */
+    if (c->ext_streams) HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemsetAsync(c->A.state, 0, 3 * c->A.n * 8, c->stream));
     c->state_zero = true;
     return 0;
@@ -1257,6 +1295,7 @@ PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
         out->reseeds += k.reseeds; out->clamps += k.clamps; out->maxiters_hits += k.maxit;
         out->particles_advanced += k.adv; out->halo_overflow += k.overflow;
         out->dropped_nonfinite += k.nonfinite;
+        out->wave_attempt_slots += k.wslots;
     }
     out->max_reach = mr;
     out->max_reach_seen = mrt;
@@ -1339,6 +1378,7 @@ PX_EXPORT int32_t picles_store_push(picles_ctx *c)
     if (c->store_count == c->store_slots) return fail(c, -3, "snapshot ring full: pop first");
     HIPCHK(c, hipSetDevice(c->device));
     { int rc = flush(c); if (rc) return rc; }
+    if (c->ext_streams) HIPCHK(c, hipDeviceSynchronize());   /* an un-fused slab step leaves its scatter on the ring's stream M */
     int slot = (c->store_head + c->store_count) % c->store_slots;
     size_t b = 3 * (size_t)c->A.n * 8;
     /* stream-ordered behind the step that produced State; the D2H leg runs beside the next steps */
@@ -1373,11 +1413,12 @@ PX_EXPORT int32_t picles_set_halo_rows(picles_ctx *c, int32_t r)
 {
     if (!c || r < 1 || r > 1024) return -1;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!c->G.single_slab && ((c->G.periodic_y && c->G.Ny <= 2 * r) || c->G.ny_loc < r))
         return fail(c, -2, "slab: periodic y axis not longer than 2*halo_rows, or fewer own rows than halo_rows");
     { int rc = flush(c); if (rc) return rc; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* the whole device, not only the context stream: after picles_slab_run_steps the scatter of the last (un-fused) step is
+     * still queued on the ring's streams, and the records it reads are about to be re-packed and freed */
+    HIPCHK(c, hipDeviceSynchronize());
     /* keep the records of the own rows: re-pack into the new ghost-row geometry */
     int oldR = c->G.R;
     size_t row_b = (size_t)6 * c->G.Nx * 8;

@@ -63,7 +63,10 @@ class HipModel:
             msg = self.lib.picles_last_error(None)
             raise K.PiclesError(f"picles_create failed (rc={rc}): {msg.decode() if msg else '?'}")
         self.h = h
-        self.gen = 0          # bumped by every call that can change the device State (LazyState validates its mirror against it)
+        self.gen = 0          # bumped by every call that changes anything on the device
+        self.state_gen = 0    # bumped by the calls that write the device State field — and only those: LazyState validates its
+                              # mirror and a recorded `State .= 0` against it (set_particles, halo resizing, advance_rows, remesh
+                              # leave State alone and must not cancel a recorded zero-fill)
         _live.add(self)
 
     # ---- lifetime ----
@@ -82,10 +85,16 @@ class HipModel:
         _check(self.lib, self.h, rc, what)
 
     # ---- inputs ----
-    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0):
+    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0, um=None, vm=None):
+        """node winds of the window [t0, t1]: one level (static), two (linear in t) or three (um, vm at (t0+t1)/2: parabola)"""
         u0, v0 = _col(u0, self.N), _col(v0, self.N)
         if u1 is not None:
             u1, v1 = _col(u1, self.N), _col(v1, self.N)
+        if um is not None:
+            um, vm = _col(um, self.N), _col(vm, self.N)
+            self._ck(self.lib.picles_set_winds3(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(um), K.dptr(vm), K.dptr(u1), K.dptr(v1), t1),
+                     "picles_set_winds3")
+            return
         self._ck(self.lib.picles_set_winds(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(u1), K.dptr(v1), t1),
                  "picles_set_winds")
 
@@ -106,21 +115,34 @@ class HipModel:
         self._ck(self.lib.picles_get_winds(self.h, *[K.dptr(a) for a in out]), "picles_get_winds")
         return [a.reshape((self.Nx, self.ny_loc), order="F") for a in out]
 
+    def get_winds_mid(self):
+        """the mid-window level of three-level winds, or None when the current winds have two levels"""
+        out = [np.empty(self.N) for _ in range(2)]
+        rc = self.lib.picles_get_winds_mid(self.h, *[K.dptr(a) for a in out])
+        if rc == 1:
+            return None
+        self._ck(rc, "picles_get_winds_mid")
+        return [a.reshape((self.Nx, self.ny_loc), order="F") for a in out]
+
     def seed(self, t0=0.0):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_seed(self.h, t0), "picles_seed")
 
     # ---- stepping ----
     def time_step(self, dt, flags=0):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_time_step(self.h, dt, flags), "picles_time_step")
 
     def run_steps(self, dt, n):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_run_steps(self.h, dt, n), "picles_run_steps")
 
     def advance(self, dt, flags=0):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_advance(self.h, dt, flags), "picles_advance")
 
     def remesh(self, dt):
@@ -132,6 +154,7 @@ class HipModel:
 
     def zero_state(self):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_zero_state(self.h), "picles_zero_state")
 
     def sync(self):
@@ -152,6 +175,7 @@ class HipModel:
 
     def scatter_remesh(self, stream=None):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_scatter_remesh(self.h, stream), "picles_scatter_remesh")
 
     def begin_fused_step(self, dt) -> bool:
@@ -163,10 +187,12 @@ class HipModel:
 
     def step_rows(self, which, stream=None):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_step_rows(self.h, which, stream), "picles_step_rows")
 
     def end_fused_step(self):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_end_fused_step(self.h), "picles_end_fused_step")
 
     def halo_send(self, side):
@@ -207,6 +233,7 @@ class HipModel:
 
     def slab_run_steps(self, dt, n, flags=K.STEP_ZERO_FIRST):
         self.gen += 1
+        self.state_gen += 1
         self._ck(self.lib.picles_slab_run_steps(self.h, dt, n, flags), "picles_slab_run_steps")
 
     def slab_exchange(self):
@@ -228,6 +255,7 @@ class HipModel:
 
     def set_state(self, s):
         self.gen += 1
+        self.state_gen += 1
         s = _col(s, 3 * self.N)
         self._ck(self.lib.picles_set_state(self.h, K.dptr(s)), "picles_set_state")
 
@@ -275,6 +303,7 @@ class HipModel:
     def scatter_particles(self, ij, xy, charge):
         """generic push_to_grid! of a particle list (ij: (n,2) int, xy: (n,2), charge: (n,3))"""
         self.gen += 1
+        self.state_gen += 1
         ij = np.ascontiguousarray(np.asarray(ij, dtype=np.int32).T)
         xy = np.ascontiguousarray(np.asarray(xy, dtype=np.float64).T)
         ch = np.ascontiguousarray(np.asarray(charge, dtype=np.float64).T)

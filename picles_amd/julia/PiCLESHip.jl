@@ -13,11 +13,11 @@
 # nothing over PCIe; `push_state_to_storage!` / `copy(model.State)` pull once per stored step.
 #
 # STATUS: UNEXECUTED.  Julia is not installed in the build container or on the GPU boxes, so this file is
-# syntax-reviewed only.  Its logic is mirrored line for line by picles_amd/models.py (`LazyState`),
+# syntax-reviewed only.  The same protocol is carried by picles_amd/models.py (`LazyState`),
 # picles_amd/timesteppers.py and picles_amd/simulations.py, which ARE executed against the same C
 # symbols (tests/test_gpu_lazy_state.py: an unobserved 10-step run! loop makes 10 fused launches,
 # <= 1 stand-alone scatter and no State transfer).  Struct layouts mirror include/picles_hip.h
-# field by field (ABI version 2).
+# field by field (ABI version 3; tests/test_capi_symbols.py holds the struct blocks below against the header).
 module PiCLESHip
 
 using PiCLES
@@ -29,7 +29,7 @@ import PiCLES.Operators.TimeSteppers: time_step!, movie_time_step!, time_step!_a
 import PiCLES.Simulations: init_particles!
 
 const libpicles = get(ENV, "PICLES_HIP_LIB", "libpicles_hip.so")
-const PICLES_ABI_VERSION = Int32(2)
+const PICLES_ABI_VERSION = Int32(3)
 
 # ---- C structs (include/picles_hip.h) ----------------------------------------------------
 struct picles_grid
@@ -68,6 +68,7 @@ struct picles_counters
     clamps::UInt64; maxiters_hits::UInt64; particles_advanced::UInt64; halo_overflow::UInt64
     max_reach::Int32; max_reach_seen::Int32
     dropped_nonfinite::UInt64
+    wave_attempt_slots::UInt64
 end
 
 const STEP_ZERO_FIRST = Int32(1)
@@ -223,7 +224,9 @@ function WaveGrowth2DHIP(; grid::TwoDCartesianGridMesh, winds, ODEsets, γ, q, I
 end
 
 # node-sample the wind closures for [t, t+Δt] by broadcast — the only place user closures run.  Static winds are
-# shipped once; time-varying winds reuse the level sampled for the end of the previous step.
+# shipped once; time-varying winds go as THREE levels (t, t+Δt/2, t+Δt: the kernels evaluate the parabola through them at
+# every Runge-Kutta stage time, the stand-in for the reference calling u_wind(x,y,t) inside the RHS,
+# particle_waves_v5.jl:494-495) and reuse the level sampled for the end of the previous step.
 function upload_winds!(model::WaveGrowth2DHIP, t, Δt)
     model.winds_static && model.winds_uploaded && return
     x, y = model.grid.data.x, model.grid.data.y
@@ -236,11 +239,13 @@ function upload_winds!(model::WaveGrowth2DHIP, t, Δt)
             model.ctx, u0, v0, t, C_NULL, C_NULL, t)
         model.winds_uploaded = true
     else
+        um = Matrix{Float64}(model.winds.u.(x, y, t + Δt / 2))
+        vm = Matrix{Float64}(model.winds.v.(x, y, t + Δt / 2))
         u1 = Matrix{Float64}(model.winds.u.(x, y, t + Δt))
         v1 = Matrix{Float64}(model.winds.v.(x, y, t + Δt))
-        rc = ccall((:picles_set_winds, libpicles), Int32,
-            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Float64),
-            model.ctx, u0, v0, t, u1, v1, t + Δt)
+        rc = ccall((:picles_set_winds3, libpicles), Int32,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64),
+            model.ctx, u0, v0, t, um, vm, u1, v1, t + Δt)
         model.wind_level = (t + Δt, u1, v1)
     end
     check(model.ctx, rc, "picles_set_winds")

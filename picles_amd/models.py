@@ -39,35 +39,46 @@ class LazyState:
                                             fused into the scatter's store; nothing crosses PCIe, the steps stay fused)
       any other write                    ->  `dirty`: the host copy is uploaded before the next step
 
-    The Julia shim (picles_amd/julia/PiCLESHip.jl, `LazyState <: AbstractArray{Float64,3}`) carries exactly this logic;
-    this class is its executed twin (tests/test_gpu_lazy_state.py)."""
+    The Julia shim (picles_amd/julia/PiCLESHip.jl, `LazyState <: AbstractArray{Float64,3}`) follows the same protocol; there
+    every device-side writer of State is a method of the model and invalidates the view itself (`after_step!`), here the
+    backend can also be driven directly, so the view validates itself against the backend's `state_gen` — a counter of the
+    calls that write the device field, and ONLY those (a recorded `State .= 0` must survive `set_particles`, halo resizing
+    and the like, and must give way to `init_particles!`, which writes the seeds' State).  tests/test_gpu_lazy_state.py and
+    tests/test_host_api.py::test_lazy_state_zero_survives_calls_that_leave_state_alone execute it."""
 
     def __init__(self, backend, shape):
         self._b, self.shape, self.dtype, self.ndim = backend, tuple(shape), np.dtype(np.float64), 3
         self._host = None
-        self._gen = getattr(backend, "gen", None)
+        self._gen = self._bgen()
         self.host_valid = False     # the host mirror equals the device field
         self.dirty = False          # the host mirror was written: upload before the next step
         self.zeroed = False         # the last write was State .= 0
         self.pulls = 0              # device -> host copies so far (what the tests count)
         self.uploads = 0
 
+    def _bgen(self):
+        """generation of the device field: `state_gen` (writers of State only) where the backend keeps one, else `gen` (any
+        mutating call); None = unknown, the mirror is re-read every time"""
+        b = self._b
+        g = getattr(b, "state_gen", None)
+        return g if g is not None else getattr(b, "gen", None)
+
     # ---- reads ----
     def _valid(self):
         # the mirror is current only while nothing has touched the device field behind our back (HipModel.gen counts the
         # calls that can; a backend without the counter is re-read every time)
-        g = getattr(self._b, "gen", None)
+        g = self._bgen()
         return self.host_valid and self._host is not None and g is not None and g == self._gen
 
     def _pull(self):
-        if self.zeroed and not self.dirty and getattr(self._b, "gen", None) == self._gen:
+        if self.zeroed and not self.dirty and self._bgen() == self._gen:
             if self._host is None:
                 self._host = np.zeros(self.shape)
                 self.host_valid = True
             return self._host
         if not (self._valid() or self.dirty):
             self._host = self._b.get_state()
-            self._gen = getattr(self._b, "gen", None)
+            self._gen = self._bgen()
             self.host_valid, self.zeroed = True, False
             self.pulls += 1
         return self._host
@@ -95,7 +106,7 @@ class LazyState:
         if value == 0:
             self.zeroed, self.dirty, self.host_valid = True, False, False
             self._host = None
-            self._gen = getattr(self._b, "gen", None)
+            self._gen = self._bgen()
         else:
             self._pull().fill(value)
             self.dirty, self.zeroed = True, False
@@ -116,12 +127,13 @@ class LazyState:
             self.uploads += 1
             self.dirty = False
             return False
-        return self.zeroed and getattr(self._b, "gen", None) == self._gen
+        # a recorded `State .= 0` stands unless something has written the device field since (init_particles!: the seeds)
+        return self.zeroed and self._bgen() == self._gen
 
     def after_step(self):
         self.host_valid, self.zeroed, self.dirty = False, False, False
         self._host = None
-        self._gen = getattr(self._b, "gen", None)
+        self._gen = self._bgen()
 
 
 def _forward(op):
@@ -198,6 +210,17 @@ def sample_winds(winds, grid, t, rows=None):
     return ev(winds.u), ev(winds.v)
 
 
+def wind_window(winds, grid, t, dt, last=None, rows=None, levels=3):
+    """node-sampled levels of the user's wind closures over the step window [t, t + dt]: (u0, v0, um, vm, u1, v1), the middle
+    pair sampled at t + dt/2 (None with levels == 2).  The kernels evaluate the parabola (levels == 3) or the straight line
+    through them at every Runge-Kutta stage time — the boundary's stand-in for the reference calling u_wind(x,y,t), v_wind(x,y,t)
+    inside the RHS (particle_waves_v5.jl:494-495).  `last` = (t1, u1, v1) of the previous window is reused as this one's level 0."""
+    u0, v0 = (last[1], last[2]) if last is not None and last[0] == t else sample_winds(winds, grid, t, rows)
+    um, vm = sample_winds(winds, grid, t + 0.5 * dt, rows) if levels >= 3 else (None, None)
+    u1, v1 = sample_winds(winds, grid, t + dt, rows)
+    return u0, v0, um, vm, u1, v1
+
+
 def _hip_backend(g, p, o, m, mask, **kw):
     from .driver import HipModel
     return HipModel(g, p, o, m, mask=mask, **kw)
@@ -208,7 +231,7 @@ class WaveGrowth2D:
                  layers: int = 1, clock=None, ODEsets: ODESettings = None, ODEinit_type="wind_sea",
                  minimal_particle=None, minimal_state=None, currents=None, periodic_boundary=True,
                  boundary_type="same", CBsets=None, movie=False,
-                 backend_factory=None, backend_kwargs=None, winds_static=None):
+                 backend_factory=None, backend_kwargs=None, winds_static=None, wind_time_levels=3):
         if layers != 1:
             raise NotImplementedError("layers > 1")
         if isinstance(winds, dict):
@@ -247,6 +270,7 @@ class WaveGrowth2D:
         self.FailedCollection = []
         # time-constant winds are detected by sampling two times unless the caller says so
         self._winds_static = winds_static
+        self.wind_time_levels = int(wind_time_levels)    # 3: t, t+Δt/2, t+Δt (parabola in t); 2: the end levels only (line)
         g, p, o, m = build_structs(grid, ODEsys, ODEsets, self.ODEdefaults, self.minimal_state,
                                    self.periodic_boundary)
         factory = backend_factory or _hip_backend
@@ -266,7 +290,7 @@ class WaveGrowth2D:
         return self._winds_static
 
     def upload_winds(self, t, dt):
-        """node-sample the wind closures for the step [t, t+dt] (lerped in t by the kernel)"""
+        """node-sample the wind closures for the step [t, t+dt]: three levels (t, t+dt/2, t+dt), interpolated in t by the kernel"""
         from .wind_emulator import GriddedWinds
         if isinstance(self.winds, GriddedWinds) and hasattr(self.backend, "set_wind_grid"):
             if self._wind_window != "device-lattice":      # once: the device samples every step itself
@@ -283,10 +307,12 @@ class WaveGrowth2D:
         if self._wind_window == (t, t + dt):
             return
         # the level sampled for the end of the previous step is the start level of this one
-        last = getattr(self, "_wind_last", None)
-        u0, v0 = (last[1], last[2]) if last is not None and last[0] == t else sample_winds(self.winds, self.grid, t)
-        u1, v1 = sample_winds(self.winds, self.grid, t + dt)
-        self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
+        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None),
+                                             levels=self.wind_time_levels)
+        if um is None:
+            self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
+        else:
+            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm)
         self._wind_window = (t, t + dt)
         self._wind_last = (t + dt, u1, v1)
 

@@ -21,7 +21,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi as K
-from .models import build_structs, sample_winds
+from .models import build_structs, sample_winds, wind_window
 
 
 def slab_rows(Ny: int, world: int, rank: int):
@@ -304,10 +304,12 @@ class SlabModel:
                 self.backend.set_winds(u, v, t)
                 self._wind_window = (t, t)
             return
-        last = getattr(self, "_wind_last", None)
-        u0, v0 = (last[1], last[2]) if last is not None and last[0] == t else sample_winds(self.winds, self.grid, t, rows)
-        u1, v1 = sample_winds(self.winds, self.grid, t + dt, rows)
-        self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
+        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), rows,
+                                             levels=getattr(self, "wind_time_levels", 3))
+        if um is None:
+            self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
+        else:
+            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm)
         self._wind_last = (t + dt, u1, v1)
 
     def seed(self):

@@ -36,6 +36,7 @@ def lib(kind: str = "libm") -> C.CDLL:
         "picles_oracle_destroy": (C.c_int32, [VP]),
         "picles_oracle_set_threads": (C.c_int32, [VP, C.c_int32]),
         "picles_oracle_set_winds": (C.c_int32, [VP, DP, DP, D, DP, DP, D]),
+        "picles_oracle_set_winds3": (C.c_int32, [VP, DP, DP, D, DP, DP, DP, DP, D]),
         "picles_oracle_seed": (C.c_int32, [VP, D]),
         "picles_oracle_advance": (C.c_int32, [VP, D]),
         "picles_oracle_remesh": (C.c_int32, [VP, D]),
@@ -136,13 +137,17 @@ class OracleModel:
             pass
 
     # --- same names as the product driver ---
-    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0):
-        u0 = np.ascontiguousarray(np.asarray(u0, dtype=np.float64).reshape(-1, order="F"))
-        v0 = np.ascontiguousarray(np.asarray(v0, dtype=np.float64).reshape(-1, order="F"))
+    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0, um=None, vm=None):
+        def col(a):
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, order="F"))
+            assert a.size == self.N, (a.size, self.N)
+            return a
+        u0, v0 = col(u0), col(v0)
         if u1 is not None:
-            u1 = np.ascontiguousarray(np.asarray(u1, dtype=np.float64).reshape(-1, order="F"))
-            v1 = np.ascontiguousarray(np.asarray(v1, dtype=np.float64).reshape(-1, order="F"))
-        self.L.picles_oracle_set_winds(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(u1), K.dptr(v1), t1)
+            u1, v1 = col(u1), col(v1)
+        if um is not None:
+            um, vm = col(um), col(vm)
+        self.L.picles_oracle_set_winds3(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(um), K.dptr(vm), K.dptr(u1), K.dptr(v1), t1)
 
     def set_metric(self, m11, m22, pc):
         a = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, order="F")) for x in (m11, m22, pc)]

@@ -345,6 +345,15 @@ CASES = {
     # all physics, C_phi = c_beta = 0.04 (what the reference's scripts pass), seed time-scale != model step
     "full_stiff": dict(dx=2000.0, dy=2500.0, DT=600.0, timestep=1800.0, C_phi=0.04, periodic_boundary=False,
                        lne_max=math.log(27), sw=ALL_ON, tfac=None),
+    # winds that are NOT linear in t inside a model step, evaluated by make_rhs at the actual stage times — the closure semantics of
+    # particle_waves_v5.jl:494-495: the time factor of tests/T04_2D_reg_test.jl:166-167 on u, cos(t 3/(3600 2π)), with the 20-minute
+    # step and the physics of BASELINE config 5 (ω Δt = 0.16: a two-level lerp of the node winds misses u by 3.2e-3 at mid-step)
+    "full_tvar": dict(dx=2000.0, dy=2500.0, DT=1200.0, timestep=1200.0, C_phi=1.81e-5, periodic_boundary=False,
+                      lne_max=math.log(27), sw=ALL_ON, tfac=lambda t: math.cos(t * 3 / (3600 * 2 * math.pi))),
+    # the same with a forcing ten times faster than anything in the reference's scripts: period 4 Δt (ω Δt = π/2).  Not a target
+    # of the stated tolerance: it measures what the three-level window of the boundary costs when the forcing is that fast
+    "full_tvar_fast": dict(dx=2000.0, dy=2500.0, DT=1200.0, timestep=1200.0, C_phi=1.81e-5, periodic_boundary=False,
+                           lne_max=math.log(27), sw=ALL_ON, tfac=lambda t: 0.6 + 0.4 * math.cos(2 * math.pi * t / 4800.0)),
 }
 STEPS = (1, 3, 6)
 

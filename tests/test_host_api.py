@@ -104,3 +104,71 @@ def test_calm_region_switches_particles_off_and_on():
     _, on1, _, st = m.backend.get_particles()
     assert on1[16:-1, 1:-1].all()
     assert m.backend.get_counters()["particles_advanced"] > 0
+
+
+class _FakeBackend:
+    """the call surface LazyState needs, with the two generation counters of picles_amd.driver.HipModel"""
+
+    def __init__(self, shape):
+        self.S = np.ones(shape)
+        self.gen = self.state_gen = 0
+        self.zero_first_seen = []
+
+    def get_state(self):
+        return self.S.copy()
+
+    def set_state(self, s):
+        self.gen += 1; self.state_gen += 1
+        self.S = np.array(s, dtype=float)
+
+    def set_particles(self):            # touches the device, leaves State alone
+        self.gen += 1
+
+    def seed(self):                     # init_particles!: writes the seeds' State
+        self.gen += 1; self.state_gen += 1
+        self.S = np.full(self.S.shape, 3.0)
+
+    def time_step(self, zero_first):
+        self.gen += 1; self.state_gen += 1
+        self.zero_first_seen.append(bool(zero_first))
+        self.S = (np.zeros_like(self.S) if zero_first else self.S) + 0.5
+
+
+def test_lazy_state_zero_survives_calls_that_leave_state_alone():
+    """`State .= 0; set_particles(...); time_step!` must start from a zeroed State (the recorded zero-fill was
+    dropped when ANY backend call bumped the generation), while `State .= 0; init_particles!; time_step!` accumulates onto the
+    seeds' State as the reference does (run.jl:199-247 writes State; TimeSteppers.jl:109-166 does not zero it)."""
+    b = _FakeBackend((4, 3, 3))
+    st = models.LazyState(b, (4, 3, 3))
+    st.fill(0.0)
+    b.set_particles()
+    assert st.before_step() is True                  # the zero-fill still stands
+    assert np.all(np.asarray(st) == 0.0)             # and a read sees zeros, not the stale device field
+    b.time_step(True); st.after_step()
+    assert np.all(np.asarray(st) == 0.5)
+    st.fill(0.0)
+    b.seed()
+    assert np.all(np.asarray(st) == 3.0)             # the seeds' State, read from the device
+    assert st.before_step() is False                 # the step accumulates onto it
+    b.time_step(False); st.after_step()
+    assert np.all(np.asarray(st) == 3.5)
+    # a backend that only keeps `gen` (any call invalidates) still never reads a stale mirror
+    b2 = _FakeBackend((2, 2, 3)); del b2.state_gen
+    st2 = models.LazyState(b2, (2, 2, 3))
+    _ = np.asarray(st2)
+    b2.set_particles()
+    b2.S[:] = 7.0
+    assert np.all(np.asarray(st2) == 7.0)
+
+
+def test_hip_model_state_gen_counts_state_writers_only():
+    """the driver's two counters, without a device: which methods bump `state_gen`"""
+    import inspect
+    from picles_amd.driver import HipModel
+    writers = {"seed", "time_step", "run_steps", "advance", "zero_state", "scatter_remesh", "step_rows", "end_fused_step",
+               "slab_run_steps", "set_state", "scatter_particles"}
+    for name, fn in inspect.getmembers(HipModel, inspect.isfunction):
+        src = inspect.getsource(fn)
+        assert ("self.state_gen += 1" in src) == (name in writers), name
+        if name in writers:
+            assert "self.gen += 1" in src, name

@@ -24,6 +24,30 @@ def test_reference_seed_literal_bitwise():
     assert s[2] == -0.00043962455576072634
 
 
+def test_second_reference_literal_is_a_windsea_seed_with_T_300():
+    """tests/S02_2D_box_mesh_grid_single_steps.jl:237 (the same line in tests/T04_2D_box_2d.jl:212) holds, in a comment, the state
+    of a failed particle: u = [-15.441984291167334, 0.006707651986269529, 0.003889144130029894, 4000.0, 2333.3333333333335].
+    No input is recorded next to it, so it cannot pin a function value — but a state (ln E, c̄gx, c̄gy) produced by
+    get_initial_windsea(U, V, T) (FetchRelations.jl:314-359) lies on a two-parameter family, and solving the oracle's restatement
+    for (|U|, T) from ln E and |c̄g| returns the script's own re-seed time scale, T = 300 s (DT = 5 min), to eight digits: a
+    consistency pin of the fetch relations' exponents and constants that is independent of the first literal."""
+    from scipy.optimize import brentq
+    lnE, cx, cy = -15.441984291167334, 0.006707651986269529, 0.003889144130029894
+    cg = math.hypot(cx, cy)
+
+    def T_for(Ua):          # the time scale that gives |c̄g| = cg at wind speed Ua (c̄g grows monotonically with T)
+        return brentq(lambda T: math.hypot(*O.windsea(Ua, 0.0, T, "libm")[1:3]) - cg, 1e-4, 1e8, xtol=1e-12, rtol=1e-14)
+
+    Ua = brentq(lambda U: O.windsea(U, 0.0, T_for(U), "libm")[0] - lnE, 0.2, 5.0, xtol=1e-14, rtol=1e-14)
+    T = T_for(Ua)
+    assert T == pytest.approx(300.0, rel=1e-7), T
+    assert Ua == pytest.approx(0.72420321, rel=1e-7), Ua
+    # the wind direction is the direction of c̄g: the seed with (U, V) = Ua (c̄x, c̄y)/|c̄g| reproduces all three numbers
+    s = O.windsea(Ua * cx / cg, Ua * cy / cg, 300.0, "libm")
+    assert s[0] == pytest.approx(lnE, abs=2e-7)            # T is 300 to ~1e-8 relative: ln E moves by ~2 dT/T
+    assert s[1] == pytest.approx(cx, rel=1e-7) and s[2] == pytest.approx(cy, rel=1e-7)
+
+
 def test_seed_pmath_and_host_within_1e13():
     ref = np.array([-19.500304989027846, 0.00043962455576072634, -0.00043962455576072634])
     for got in (O.windsea(0.1, -0.1, 300.0, "pmath"), np.array(FR.get_initial_windsea(0.1, -0.1, 300.0, True)[:3])):

@@ -30,7 +30,15 @@ GEN = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(GEN)          # case definitions only (mesh, mask, winds); its Model class is not used here
 
 # tolerance on e (relative to the node value, floored at 1e-6 of the plane maximum), on c̄g, per case
-TOL = {"pic_only": (1e-12, 1e-12), "full_nonstiff": (1e-3, 5e-4), "full_stiff": (2e-2, 1e-2), "sphere": (5e-3, 2.5e-3)}
+TOL = {"pic_only": (1e-12, 1e-12), "full_nonstiff": (1e-3, 5e-4), "full_stiff": (2e-2, 1e-2), "sphere": (5e-3, 2.5e-3),
+       # winds NOT linear in t inside a model step, the fixture evaluating the closure at the stage times (particle_waves_v5.jl:494-495):
+       # cos(3t/(3600·2π)) of T04_2D_reg_test.jl:167 with the 20-minute step of BASELINE config 5 — the stated 1e-3 holds with the
+       # three-level window of the boundary (picles_set_winds3); the forcing with period 4 Δt is ten times faster than anything in
+       # the reference's scripts and is held at the measured level (test_what_the_third_wind_level_buys has the numbers)
+       "full_tvar": (1e-3, 5e-4), "full_tvar_fast": (2e-2, 1e-2)}
+# DP5 over a 20-minute step is solver-limited, not wind-limited: 2.0e-3 at the worst node (median 1.4e-4) with abstol 1e-4 /
+# reltol 1e-3, 7e-6 with the tolerances tightened (test_what_the_third_wind_level_buys); the default solver is within 1.6e-4
+TOL_SOLVER = {("full_tvar", "DP5"): (3e-3, 1.5e-3)}
 # The steppers control the error of ln e (abstol 1e-4 + reltol 1e-3 |ln e|), so "1e-3 on e" holds where |ln e| = O(1) and
 # for 10-minute model steps.  The sphere case takes ONE-HOUR steps under a 14 m/s wind blob next to
 # seeds of e ~ 2e-7 (ln e = -15): measured against the converged solution, DP5 is within 3e-3 in the blob (AutoTsit5 1e-3,
@@ -58,7 +66,7 @@ def _cfg_sphere(solver):
         Δt=c["DT"], n_steps=6, mode="run")
 
 
-def _cfg(name, solver):
+def _cfg(name, solver, wind_time_levels=3):
     if name == "sphere":
         return _cfg_sphere(solver)
     c = GEN.CASES[name]
@@ -75,7 +83,7 @@ def _cfg(name, solver):
     return SimpleNamespace(
         model=dict(grid=grid, winds=SimpleNamespace(u=u, v=v), ODEsys=psys, ODEsets=sets, ODEinit_type="wind_sea",
                    periodic_boundary=c["periodic_boundary"], boundary_type="same", movie=False,
-                   winds_static=(c["tfac"] is None)),
+                   winds_static=(c["tfac"] is None), wind_time_levels=wind_time_levels),
         Δt=c["DT"], n_steps=6, mode="run")
 
 
@@ -86,12 +94,13 @@ def _rel(a, ref, floor):
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("name,solver", [("pic_only", "DP5"), ("full_nonstiff", "DP5"), ("full_nonstiff", "AutoTsit5"),
                                          ("full_stiff", "DP5"), ("full_stiff", "Tsit5"), ("full_stiff", "AutoTsit5"),
-                                         ("sphere", "DP5"), ("sphere", "AutoTsit5")])
+                                         ("sphere", "DP5"), ("sphere", "AutoTsit5"),
+                                         ("full_tvar", "DP5"), ("full_tvar", "AutoTsit5"), ("full_tvar_fast", "AutoTsit5")])
 def test_whole_step_against_independent_restatement(name, solver, backend):
     fx = np.load(GOLD / f"step2d_{name}.npz")
     cfg = _cfg(name, solver)
     m = make_model(cfg, backend)
-    tol_e, tol_c = TOL[name]
+    tol_e, tol_c = TOL_SOLVER.get((name, solver), TOL[name])
     np.testing.assert_array_equal(np.asarray(m.grid.data.mask), fx["mask"])           # mask classes (mask_utils.jl)
     np.testing.assert_allclose(m.minimal_state, fx["minimal_state"], rtol=1e-13)
     initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
@@ -135,6 +144,46 @@ def test_whole_step_against_independent_restatement(name, solver, backend):
             assert np.abs(z[..., 0][live] - zr[..., 0][live]).max() <= tol_e                     # ln e: absolute = relative on e
             cmax = np.abs(zr[..., 1:3][live]).max()
             assert np.abs(z[..., 1:3][live] - zr[..., 1:3][live]).max() <= tol_c * cmax
+
+
+def _state_errors(name, solver, backend, levels, tight):
+    """max relative error on e of the scattered field against the fixture after steps 1, 3, 6"""
+    fx = np.load(GOLD / f"step2d_{name}.npz")
+    cfg = _cfg(name, solver, wind_time_levels=levels)
+    if tight:      # take the stepper's own error out of the picture: what is left is the wind window's
+        cfg.model["ODEsets"].abstol, cfg.model["ODEsets"].reltol = 1e-10, 1e-9
+    m = make_model(cfg, backend)
+    initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    out = {}
+    for k in range(1, 7):
+        m.backend.zero_state()
+        time_step_advance(m, cfg.Δt)
+        if f"state{k}" in fx:
+            ref = fx[f"state{k}"]
+            floor = 1e-6 * np.abs(ref).max(axis=(0, 1), keepdims=True)
+            out[k] = float(_rel(np.asarray(m.State), ref, floor)[..., 0].max())
+        time_step_remesh(m, cfg.Δt)
+        m.backend.tick(cfg.Δt)
+        m.clock.time += cfg.Δt
+    return out
+
+
+@pytest.mark.parametrize("backend", [("libm", 0), ("pmath", 1)])
+def test_what_the_third_wind_level_buys(backend):
+    """the reference's RHS calls u_wind(x,y,t) at every stage time (particle_waves_v5.jl:494-495); the boundary hands
+    over node-sampled levels.  With the stepper's own error taken out (abstol 1e-10, reltol 1e-9) what remains against the fixture —
+    which evaluates the closure cos(3t/(3600·2π)) (T04_2D_reg_test.jl:167) at the stage times, Δt = 20 min as in BASELINE config 5 —
+    is the error of the wind window: two levels (linear in t) miss the stated 1e-3 by an order of magnitude, three levels
+    (the parabola, picles_set_winds3) sit three orders below it.  Measured (oracle A): 7.4e-3 / 9.3e-3 / 1.5e-2 after steps
+    1 / 3 / 6 against 3.1e-6 / 7.3e-6 / 7.0e-6."""
+    two = _state_errors("full_tvar", "AutoTsit5", backend, 2, True)
+    three = _state_errors("full_tvar", "AutoTsit5", backend, 3, True)
+    assert min(two.values()) > 5e-3 and max(two.values()) < 3e-2, two
+    assert max(three.values()) < 2e-5, three
+    # the forcing with period 4 Δt (ω Δt = π/2): the parabola is worth a factor 15-100, and is what limits that case
+    two_f = _state_errors("full_tvar_fast", "AutoTsit5", backend, 2, True)
+    three_f = _state_errors("full_tvar_fast", "AutoTsit5", backend, 3, True)
+    assert max(three_f.values()) < 2e-2 and min(two_f.values()) > 10 * min(three_f.values()), (two_f, three_f)
 
 
 def test_spherical_metric_matches_the_independent_restatement():
