@@ -1160,7 +1160,10 @@ static void po_integrate(const po_model *M, int64_t idx, double z[5], double *qo
 static inline void po_index_weight(double zp, int32_t i_node, int64_t idx[2], double w[2])
 {
     double b = floor(zp);
-    int64_t ib = (int64_t)b;
+    /* Julia's Int(floor(x)) throws beyond the Int64 range; a C conversion there is undefined (found with UBSan on the hostile
+     * scenarios, where runaway particles reach 1e19 cells and more): saturate well inside the range, the wrap / drop rules
+     * below treat the result like any other far-away cell */
+    int64_t ib = (int64_t)((b > 9.0e18) ? 9.0e18 : (b < -9.0e18) ? -9.0e18 : b);
     double wc = rint((zp - b) * 1e6) / 1e6; /* round(·, digits=6) */
     idx[0] = ib + i_node;
     idx[1] = ib + i_node + 1;
@@ -1208,7 +1211,7 @@ static int po_particle_to_node(po_model *M, int32_t i, int32_t j, const double z
     d = llabs(xi[1] - i); if (d > r) r = d;
     d = llabs(yi[0] - j); if (d > r) r = d;
     d = llabs(yi[1] - j); if (d > r) r = d;
-    return (int)r;
+    return (r > 0x7fffffff) ? 0x7fffffff : (int)r;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1617,8 +1620,8 @@ static void po_write_record(po_model *M, int64_t idx, int *reach_out, int *overf
         double w[2];
         po_index_weight(z[3], 0, xi, w);
         po_index_weight(z[4], 0, yi, w);
-        int r = (int)((xi[0] < 0) ? -xi[0] : xi[0] + 1);
-        int ry = (int)((yi[0] < 0) ? -yi[0] : yi[0] + 1);
+        int64_t r64 = (xi[0] < 0) ? -xi[0] : xi[0] + 1, ry64 = (yi[0] < 0) ? -yi[0] : yi[0] + 1;
+        int r = (r64 > 0x3fffffff) ? 0x3fffffff : (int)r64, ry = (ry64 > 0x3fffffff) ? 0x3fffffff : (int)ry64;
         if (ry > r) r = ry;
         if (r > *reach_out) *reach_out = r;
         if (!M->single_slab && r > M->R) (*overflow)++;
@@ -1776,6 +1779,8 @@ PO_EXPORT int32_t picles_oracle_scatter_rows(po_model *M, int32_t do_remesh)
     int movie = (flags & PICLES_STEP_MOVIE) != 0 && do_remesh;
     int accum = (flags & PICLES_STEP_ZERO_FIRST) ? 0 : 1;
     int R = M->single_slab ? (M->cnt.max_reach > 1 ? M->cnt.max_reach : 1) : M->R;
+    if (R > 4096) return -6;   /* a runaway particle: the candidate tables of the pull (2R+1 entries on the stack) are not meant for it;
+                                  the sequential push (picles_oracle_time_step) has no such limit */
     double *ns = (double *)malloc(3 * M->N * 8);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(M->nthreads)

@@ -1232,8 +1232,9 @@ static int d2h(picles_ctx *c, void *dst, const void *src, size_t bytes)
     HIPCHK(c, hipSetDevice(c->device));
     { int rc = flush(c); if (rc) return rc; }
     HIPCHK(c, hipDeviceSynchronize());   /* kernels may have run on caller-provided streams */
-    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* a BLOCKING copy into the caller's (pageable) buffer: when this returns the runtime has written the last byte of it and
+     * holds no staging reference to it any more — the caller may free the buffer at once (ctypes / ccall hosts do) */
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 static int h2d(picles_ctx *c, void *dst, const void *src, size_t bytes)

@@ -307,8 +307,10 @@ class WaveGrowth2D:
         if self._wind_window == (t, t + dt):
             return
         # the level sampled for the end of the previous step is the start level of this one
-        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None),
-                                             levels=self.wind_time_levels)
+        # gridded winds are linear in t between their knots by definition (Interpolations.linear_interpolation,
+        # Utils/WindEmulator.jl:18-43): two levels are their exact form, and what the device-side sampler hands the kernels
+        levels = 2 if isinstance(self.winds, GriddedWinds) else self.wind_time_levels
+        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), levels=levels)
         if um is None:
             self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
         else:

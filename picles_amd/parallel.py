@@ -304,8 +304,8 @@ class SlabModel:
                 self.backend.set_winds(u, v, t)
                 self._wind_window = (t, t)
             return
-        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), rows,
-                                             levels=getattr(self, "wind_time_levels", 3))
+        levels = 2 if isinstance(self.winds, GriddedWinds) else getattr(self, "wind_time_levels", 3)      # see models.upload_winds
+        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), rows, levels=levels)
         if um is None:
             self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
         else:
