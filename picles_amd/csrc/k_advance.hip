@@ -1,5 +1,6 @@
 /* k_advance.hip — the stand-alone advance kernel and its instantiations */
 #define PICLES_TABLEAU_SMEM(FAST, AUTO) ((FAST) && !(AUTO))      /* Butcher tableau through scalar loads in the four-wave flavours (physics.h) */
+#define PICLES_ROS_KARGS 1                          /* the Rosenbrock23 branch re-reads KParams from the kernarg segment (physics.h) */
 #include "kernels.h"
 
 /* the kernel arguments as the kernarg segment lays them out (kargs_reload, kernels.h: behind the RK loop they are read again
@@ -29,9 +30,11 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
     pm_device_init();
     long long t = 0;
     bool active = rows_index(G, r0, n0, r1, n1, t);
+    if (active) rmap_clear_ahead(A, t);      /* every node of the rows, stepped or not: the clear must reach every tile */
     unsigned char pf = active ? A.pflags[t] : 0;
     active = active && (pf & PF_STEPPED);
     StepStats S = {{0u, 0u, 0u, 0}, 0u, 0u, 0u, 0u, 0u, 0u, 0};
+    int rtile = -1;
     if (active) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
         Vec5 z;
@@ -52,6 +55,7 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
             Aq.dtn[tq] = dtn;
             Aq.status[tq] = status;
             write_record(Gq, Aq, iq, jlq, pfq, on, z, S);
+            rtile = (int)(tq >> 6);
         };
         if constexpr (FAST && !AUTO) {
             /* the four-wave flavours: what is needed again only behind the loop waits in LDS, and the kernel arguments are read
@@ -76,7 +80,7 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
             finish(P, G, A, t, i, jl, pf, t_start, DT, status);
         }
     }
-    flush_stats(A, S);
+    flush_stats(A, S, rtile);
 }
 
 #define LAUNCH_ADV(F, S, M) do { if (solver == 2) hipLaunchKernelGGL((k_advance<F, S, M, true, true>), L.grid, L.block, 0, L.stream, *L.P, *L.G, *L.A, L.t_start, L.DT, L.r0, L.n0, L.r1, L.n1); \

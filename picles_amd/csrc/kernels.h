@@ -58,6 +58,12 @@ struct Arrays {
      * (reach_counters(A) = (int *)(A.cnt + NSLOTS)): mr[0..4] rotate with the steps, mr[5] is the running maximum since the last
      * reset; mr_idx = read | written << 4 | cleared << 8. */
     int mr_idx;
+    /* local scatter reach: one int per 64 consecutive particles (index space: tile = t >> 6), the largest reach any of them had
+     * in the advance that wrote the records — what lets the pull of a node look at 9 candidates where its neighbourhood is calm
+     * or slow and at (2R+1)² only where particles really travel R cells (BASELINE config 5: reach 4 in the strong-wind corner,
+     * 1 in the calm half).  Five buffers of ntile ints rotating with the reach counters above (same three indices). */
+    int ntile;
+    int *rmap;
     long long n;             /* Nx * ny_loc */
 };
 
@@ -268,18 +274,42 @@ __device__ __forceinline__ void write_record(const GridP &G, const Arrays &A, in
 /* statistics: one atomic per wave into the wave's slot.  The 0/1 flags are counted with a ballot +
  * scalar popcount (no cross-lane traffic), the step counters with two 64-bit butterfly sums
  * (accepted and rejected steps share one word), the reach with a ballot ladder. */
-__device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S)
+/* rtile: the reach-map tile (t >> 6) of a lane whose particle left a record this step, -1 otherwise */
+__device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S, int rtile = -1)
 {
     unsigned long long s_rhs = wave_sum_u64(S.st.rhs);
     unsigned long long s_ar = wave_sum_u64(((unsigned long long)S.st.acc << 32) | S.st.rej);
     unsigned long long b_adv = __ballot(S.adv != 0), b_res1 = __ballot(S.reseeds == 1), b_res2 = __ballot(S.reseeds >= 2);
     unsigned long long b_cl = __ballot(S.clamps != 0), b_mx = __ballot(S.maxit != 0), b_ov = __ballot(S.overflow != 0);
     unsigned long long b_nf = __ballot(S.nonfinite != 0);
-    const int m_att = wave_max_i32((int)(S.st.acc + S.st.rej));        /* the attempts this wave ran: its slowest lane's */
+    /* the attempts this wave ran = its slowest lane's: a ballot ladder from lane 0's count (no cross-lane data movement; a shuffle
+     * reduction is six dependent LDS permutes at the very end of the wave's life, which the three-wave kernels do not hide) */
+    const int att_ = (int)(S.st.acc + S.st.rej);
+    int m_att = __builtin_amdgcn_readfirstlane(att_);
+    while (__ballot(att_ > m_att)) m_att++;
     int m_reach = 0;
     if (__ballot(S.reach > 0)) {
         m_reach = 1;
         while (__ballot(S.reach > m_reach)) m_reach++;   /* reach is 1 in all but exotic steps: one extra ballot */
+    }
+    if (m_reach > 0) {
+        /* the wave's reach into the map entry of its tile.  A wave covers 64 consecutive particles: one tile when the launch is
+         * aligned with the tiles (the row length a multiple of 64), two otherwise — the loop runs once or twice */
+        int *const rm = A.rmap + (size_t)((A.mr_idx >> 4) & 15) * (size_t)A.ntile;
+        int mine = (S.reach > 0) ? rtile : -1;
+        unsigned long long todo = __ballot(mine >= 0);
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int tile0 = __builtin_amdgcn_readlane(mine, lead);
+            const bool in = (mine == tile0);
+            int r0 = 1;
+            while (__ballot(in && S.reach > r0)) r0++;
+            /* fire and forget: no load first — every tile has its own address (a cold line: the round trip would sit at the
+             * end of every wave's life: measured +5 % on the three-wave kernels), and at most two waves write an entry */
+            if ((int)(threadIdx.x & 63) == lead) atomicMax(rm + tile0, r0);
+            if (in) mine = -1;
+            todo = __ballot(mine >= 0);
+        }
     }
     if ((threadIdx.x & 63) == 0) {
         DevCounters *c = A.cnt + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (NSLOTS - 1));
@@ -592,6 +622,7 @@ __device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i,
     else if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
     else if (R == 2) pull_node<2>(G, A, i, jl, 2, s0, s1, s2);
     else if (R == 3) pull_node<3>(G, A, i, jl, 3, s0, s1, s2);     /* a fully developed sea under strong winds */
+    else if (R == 4) pull_node<4>(G, A, i, jl, 4, s0, s1, s2);     /* 20-minute steps (BASELINE config 5) */
     else pull_node<0>(G, A, i, jl, R, s0, s1, s2);
 }
 
@@ -607,6 +638,42 @@ __device__ __forceinline__ int pull_reach(const GridP &G, const Arrays &A, int j
     return (G.Rp > 0 && m > G.Rp) ? G.Rp : m;
 }
 
+
+/* every tile's first particle clears the tile's entry in the map two steps ahead (nobody reads or writes that buffer during this
+ * step: the rotation of Arrays::mr_idx); every node is covered by exactly one launch per step, so every entry is cleared once */
+__device__ __forceinline__ void rmap_clear_ahead(const Arrays &A, long long t)
+{
+    if ((t & 63) == 0) A.rmap[(size_t)((A.mr_idx >> 8) & 15) * (size_t)A.ntile + (size_t)(t >> 6)] = 0;
+}
+
+/* The reach the pull of node (i, jl) must cover: the largest reach of any particle that can land on it.  Rg (pull_reach: the
+ * grid-wide maximum of the last advance, or halo_rows for the edge rows of a slab) bounds where such particles sit; among the
+ * tiles that intersect that window the map knows how far particles really went.  Any reach >= the true one gives the same
+ * bits (candidates that do not land on the node never match; the visiting order of those that do is unchanged), so the result is
+ * made wave-uniform — the maximum over the ACTIVE lanes of the wave, by a ballot ladder (callers sit inside `if (active)`: a
+ * shuffle would read the registers of inactive lanes) — and the reach dispatch of pull_any stays a scalar branch.  Nodes whose
+ * window touches a wrap, an open edge or ghost rows keep Rg. */
+__device__ __forceinline__ int pull_reach_local(const GridP &G, const Arrays &A, int i, int jl, int Rg)
+{
+    int R = Rg;
+    const int j = jl + G.j_begin;
+    const bool edge_row = G.Rp > 0 && (jl < G.R || jl >= G.ny_loc - G.R);          /* fed by a neighbour's particles: no local knowledge */
+    if (Rg >= 2 && Rg <= 31 && !edge_row && i - Rg >= 0 && i + Rg < G.Nx && jl - Rg >= 0 && jl + Rg < G.ny_loc &&
+        j - Rg >= 0 && j + Rg < G.Ny) {
+        const int *const rm = A.rmap + (size_t)(A.mr_idx & 15) * (size_t)A.ntile;
+        int m = 1;
+        long long t0 = (long long)(jl - Rg) * G.Nx + (i - Rg);
+        for (int dj = -Rg; dj <= Rg; dj++, t0 += G.Nx) {                           /* 2 Rg + 1 <= 63 columns: at most two tiles per row */
+            const int a = rm[t0 >> 6], b = rm[(t0 + 2 * Rg) >> 6];
+            m = max(m, max(a, b));
+        }
+        R = min(m, Rg);
+    }
+    if (Rg < 2) return Rg;
+    int m = 1;
+    while (__ballot(R > m)) m++;          /* <= Rg - 1 rounds */
+    return m;
+}
 
 /* launchers of the kernel families that live in their own translation units (k_step_*.hip, k_advance.hip) */
 struct StepLaunch {

@@ -569,6 +569,25 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     }
 }
 
+/* The Rosenbrock23 attempt reads its parameters afresh from the kernarg segment (PICLES_ROS_KARGS: translation units whose kernels
+ * take KParams as their FIRST argument — k_step, k_advance).  The branch is entered by a minority of attempts, but what it alone
+ * needs — C_φ, 2/r_g², 1/e_T⁴, C_α, the unfolded constants of the Jacobian — would otherwise sit in scalar registers through all
+ * seven Tsit5 stages of every attempt; the scalar file overflows there and its spill code (v_readlane / v_writelane) is VALU work
+ * inside the loop.  Behind an opaque copy of the segment pointer the loads stay inside the branch (scalar loads, K$ hits). */
+#ifndef PICLES_ROS_KARGS
+#define PICLES_ROS_KARGS 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && PICLES_ROS_KARGS
+__device__ __forceinline__ const KParams &ros_params(const KParams &)
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    __asm__ volatile("" : "+s"(p));
+    return *(const KParams *)p;
+}
+#else
+PM_HD const KParams &ros_params(const KParams &P) { return P; }
+#endif
+
 /* one attempted Rosenbrock23 step of size h from (z, f0) at absolute time t: returns EEst² (kernel-order norm),
  * un = the new state, f2 = f(un, t+h) (the next step's FSAL), eig = ||J||_inf */
 template <bool FAST, bool STATIC, bool METRIC>
@@ -797,7 +816,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         Vec5 un;
         double EE2;
         if (AUTO && as_stiff) {
-            EE2 = ros23_try<FAST, STATIC, METRIC>(P, w, W, z, k1, t, h, ipx, ipy, pc, un, k7, eig, st);
+            EE2 = ros23_try<FAST, STATIC, METRIC>(ros_params(P), w, W, z, k1, t, h, ipx, ipy, pc, un, k7, eig, st);
             eig_nu = eig * eig; eig_nd = 1.0;     /* ||J||_inf */
         } else {
         double gl, gx, gy;      /* stage state (lne, c̄x, c̄y) */
@@ -919,7 +938,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             lq = pm_fmax_c(le, PI_LNQOLDINIT);
             dt = h * qi;
             z = un;
-            k1 = k7;
+                    k1 = k7;
             tr = last ? DT : tr + h;
             if (z.lne != z.lne || z.cx != z.cx || z.cy != z.cy || z.x != z.x || z.y != z.y) break;
         } else {

@@ -104,11 +104,12 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
     if (REMESH) pm_device_init();
     long long t = (long long)xcd_block() * blockDim.x + threadIdx.x;
     unsigned int reseeds = 0;
-    if (t < A.n) {
+    const bool active = t < A.n;
+    if (active) {
         int i = (int)(t % G.Nx), jl = (int)(t / G.Nx);
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if (accum) { s0 = A.state[t]; s1 = A.state[t + A.n]; s2 = A.state[t + 2 * A.n]; }
-        pull_any(G, A, i, jl, pull_reach(G, A, jl), s0, s1, s2);
+        pull_any(G, A, i, jl, pull_reach_local(G, A, i, jl, pull_reach(G, A, jl)), s0, s1, s2);
         if (movie) {
             A.movie[t] = s0; A.movie[t + A.n] = s1; A.movie[t + 2 * A.n] = s2;
             A.state[t] = 0.0; A.state[t + A.n] = 0.0; A.state[t + 2 * A.n] = 0.0;
@@ -684,6 +685,9 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
         CK(hipMalloc(&c->rec_buf[k], rec_bytes(c)));
         CK(hipMemset(c->rec_buf[k], 0, rec_bytes(c)));
     }
+    A.ntile = (int)((n + 63) / 64);
+    CK(hipMalloc(&A.rmap, (size_t)5 * A.ntile * sizeof(int)));      /* local reach map, five rotating buffers (kernels.h: Arrays::rmap) */
+    CK(hipMemset(A.rmap, 0, (size_t)5 * A.ntile * sizeof(int)));
     CK(hipMalloc(&c->d_mask, n));
     CK(hipMemset(A.state, 0, 3 * n * 8)); CK(hipMemset(A.movie, 0, 3 * n * 8)); CK(hipMemset(A.z, 0, 5 * n * 8));
     CK(hipMemset(A.qold, 0, n * 8)); CK(hipMemset(A.dtn, 0, n * 8)); CK(hipMemset(A.on, 0, n)); CK(hipMemset(A.status, 0, n * 4));
@@ -708,7 +712,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
     if (c->um_buf) { hipFree(c->um_buf); hipFree(c->vm_buf); }
-    hipFree(A.cnt); hipFree(c->d_mask);
+    hipFree(A.cnt); hipFree(A.rmap); hipFree(c->d_mask);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
     for (int k = 0; k < 2; k++) hipFree(c->rec_buf[k]);
 
@@ -903,6 +907,7 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
     }
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
     HIPCHK(c, hipMemsetAsync(c->mr_buf[0] + 5, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->A.rmap, 0, (size_t)5 * c->A.ntile * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, arrays_for(c, 0, 0), c->d_mask, c->od.timestep);
     HIPCHK(c, hipGetLastError());
     c->state_zero = false;
@@ -1298,6 +1303,14 @@ PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
         out->dropped_nonfinite += k.nonfinite;
         out->wave_attempt_slots += k.wslots;
     }
+#ifdef PICLES_PHASE_CLOCK
+    {
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, nw = 0;
+        for (const DevCounters &k : d) { p0 += k.pad_[0]; p1 += k.pad_[1]; p2 += k.pad_[2]; nw += k.pad_[3]; }
+        if (nw) fprintf(stderr, "PHASE_CLOCK waves %llu: prologue+pull %.0f, RK+guards %.0f, record+stats %.0f cycles per wave (lane 0's view)\n",
+                        nw, (double)p0 / nw, (double)p1 / nw, (double)p2 / nw);
+    }
+#endif
     out->max_reach = mr;
     out->max_reach_seen = mrt;
     return 0;

@@ -1,0 +1,55 @@
+"""BASELINE config 5 (2048², growing / decaying winds with the time factor cos(3t/(3600·2π)), 20-minute steps, default solver) with the
+forcing as a device lattice: per-launch kernel times, RHS throughput, the lane efficiency of the adaptive advance (device counters:
+Σ lane RK attempts ÷ Σ 64 × wave maximum) and, for scale, the homogeneous box of the same size and solver.  One JSON line per run.
+    python scripts/cfg5_profile.py [steps]        (under rocprofv3 for profiles/r3_cfg5_*)"""
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+from picles_amd import configs
+from picles_amd.models import WaveGrowth2D
+from picles_amd.simulations import Simulation, initialize_simulation
+from picles_amd.timesteppers import time_step
+from picles_amd.wind_emulator import wind_interpolator
+
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 58
+
+
+def run(name, cfg, warm, steps):
+    m = WaveGrowth2D(**cfg.model)
+    initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    for _ in range(warm):
+        time_step(m, cfg.Δt, zero_first=True)
+    m.backend.sync(); m.backend.reset_counters(); m.backend.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        time_step(m, cfg.Δt, zero_first=True)
+    m.backend.sync()
+    dt = time.perf_counter() - t0
+    tim, c = m.backend.get_timing(), m.backend.get_counters()
+    s = np.sort(m.backend.get_timing_samples(0))
+    att = c["steps_accepted"] + c["steps_rejected"]
+    out = {"run": name, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "k_step_ms": {"mean": tim["advance_ms"] / max(tim["advance_launches"], 1), "min": float(s[0]), "median": float(np.median(s)), "max": float(s[-1])},
+           "particles_on_per_step": c["particles_advanced"] / steps, "rhs_per_particle_step": c["rhs_evals"] / max(c["particles_advanced"], 1),
+           "rhs_per_s": c["rhs_evals"] / dt, "rhs_per_kernel_s": c["rhs_evals"] / (1e-3 * tim["advance_ms"]),
+           "attempts_per_particle_step": att / max(c["particles_advanced"], 1),
+           "lane_efficiency": att / max(c.get("wave_attempt_slots", 0), 1), "max_reach": c["max_reach_seen"], "reseeds": c["reseeds"]}
+    print(json.dumps(out), flush=True)
+    return out
+
+
+cfg = configs.growing_decaying_winds(n=2048)
+g = cfg.model["grid"]
+x = g.data.x[:, 0]; y = np.array([0.0, g.data.y[0, -1]]); t = np.arange(0.0, (STEPS + 6) * cfg.Δt, cfg.Δt)
+X, Y, T = np.meshgrid(x, y, t, indexing="ij")
+w = wind_interpolator(dict(x=x, y=y, t=t, u=cfg.model["winds"].u(X, Y, T), v=cfg.model["winds"].v(X, Y, T)))
+cfg.model["winds"] = w; cfg.model["ODEsys"].u, cfg.model["ODEsys"].v = w.u, w.v
+a = run("cfg5 2048x2048 growing/decaying winds, device lattice, AutoTsit5", cfg, 2, STEPS)
+box = configs.box4096(n=2048)
+box.model["ODEsets"].solver = "AutoTsit5"
+b = run("homogeneous periodic 2048x2048 box, winds (10,10), AutoTsit5 (bench06 physics)", box, 5, 20)
+print(json.dumps({"cfg5_rhs_per_kernel_s_over_box": a["rhs_per_kernel_s"] / b["rhs_per_kernel_s"], "cfg5_rhs_per_s_over_box": a["rhs_per_s"] / b["rhs_per_s"]}))
