@@ -146,6 +146,9 @@ def main():
                          "interior launches on two streams, the halo blocks sent to ourselves every step")
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the slab exchange from Python (torch.distributed P2P per step) instead of the native ring")
+    ap.add_argument("--native-ring", action="store_true",
+                    help="with --backend gloo: the library's own step loop (picles_slab_run_steps) over whatever communicator "
+                         "PICLES_CCL_LIB names — the rehearsal of the N > 1 launch path on one GPU (tests/native/shm_ccl.cpp)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with all ranks on ONE GPU (halo staged through the host)")
     args = ap.parse_args()
@@ -212,7 +215,7 @@ def main():
         cfg.model["ODEsets"].solver = solver
         model = SlabModel(cfg.model, rank, world, device=local_rank, halo_rows=args.halo,
                           ring_of_one=args.ring_of_one,
-                          native_ring=None if (args.backend == "nccl" and not args.python_loop) else False)
+                          native_ring=True if args.native_ring else (None if (args.backend == "nccl" and not args.python_loop) else False))
         model.seed()
         model.run_steps(cfg.Δt, W_, flags)
         model.backend.reset_counters()

@@ -31,21 +31,23 @@ def slab_rows(Ny: int, world: int, rank: int):
     return j0, j0 + base + (1 if rank < rem else 0)
 
 
-_uid_round = [0]
-
-
 def share_unique_id(uid, rank: int) -> bytes:
-    """hand rank 0's 128-byte ncclUniqueId to every rank through the key-value store of the default process group (the
-    rendezvous TCP store: no collective, no device traffic — the only thing torch.distributed does for the native ring).
-    Called collectively; every call uses a fresh key."""
+    """hand rank 0's 128-byte ncclUniqueId to every rank: one broadcast of a uint8 tensor over the default process group (the
+    public route: no private c10d store).  The first byte says whether rank 0 had an id to give — if not, EVERY rank raises here,
+    before anybody can enter the communicator's blocking rendezvous alone.  Called collectively."""
+    import torch
     import torch.distributed as dist
-    store = dist.distributed_c10d._get_default_store()
-    key = f"picles_slab_uid_{_uid_round[0]}"
-    _uid_round[0] += 1
-    if rank == 0:
-        store.set(key, bytes(uid))
-        return bytes(uid)
-    return bytes(store.get(key))          # blocks until rank 0 has published it
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    buf = torch.zeros(K.SLAB_ID_BYTES + 1, dtype=torch.uint8)
+    if rank == 0 and uid is not None:
+        buf[0] = 1
+        buf[1:] = torch.frombuffer(bytearray(uid), dtype=torch.uint8)
+    buf = buf.to(dev)
+    dist.broadcast(buf, src=0)
+    raw = bytes(buf.cpu().numpy().tobytes())
+    if raw[0] != 1:
+        raise K.PiclesError("rank 0 could not draw a communicator id (picles_slab_unique_id failed there)")
+    return raw[1:]
 
 
 class _DevBlock:
@@ -259,9 +261,16 @@ class SlabModel:
                     print("[picles_amd] native slab ring unavailable on some rank; using the torch.distributed exchange", file=sys.stderr, flush=True)
                 return
         try:
-            uid = b.slab_unique_id() if rank == 0 else None
+            uid = None
+            if rank == 0:
+                try:
+                    uid = b.slab_unique_id()
+                except K.PiclesError as e:
+                    if world == 1:
+                        raise
+                    print(f"[picles_amd] rank 0: no communicator id ({e})", file=sys.stderr, flush=True)
             if world > 1:
-                uid = share_unique_id(uid, rank)
+                uid = share_unique_id(uid, rank)      # collective; raises on EVERY rank if rank 0 had nothing to share
             b.slab_comm_init(uid, rank, world)
             self.native = True
         except K.PiclesError as e:
