@@ -1,5 +1,13 @@
 /* k_advance.hip — the stand-alone advance kernel and its instantiations */
+#ifndef PICLES_TABLEAU_SMEM
 #define PICLES_TABLEAU_SMEM(FAST, AUTO) ((FAST) && !(AUTO))      /* Butcher tableau through scalar loads in the four-wave flavours (physics.h) */
+#endif
+/* every flavour parks (particle index, node, flags) in LDS and reads its arguments again behind the RK loop instead of keeping
+ * them in scalar registers across it (k_step.inc has the reasons): scalar spills 61-105 -> 12-18 in the general-physics and
+ * auto-switching flavours (the general-physics auto-switching pair keeps ~100: its Jacobian reads most of KParams) */
+#ifndef PICLES_ADV_RELOAD
+#define PICLES_ADV_RELOAD(FAST, AUTO) true
+#endif
 #define PICLES_ROS_KARGS 1                          /* the Rosenbrock23 branch re-reads KParams from the kernarg segment (physics.h) */
 #include "kernels.h"
 
@@ -57,8 +65,8 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
             write_record(Gq, Aq, iq, jlq, pfq, on, z, S);
             rtile = (int)(tq >> 6);
         };
-        if constexpr (FAST && !AUTO) {
-            /* the four-wave flavours: what is needed again only behind the loop waits in LDS, and the kernel arguments are read
+        if constexpr (PICLES_ADV_RELOAD(FAST, AUTO)) {
+            /* what is needed again only behind the loop waits in LDS, and the kernel arguments are read
              * again from the kernarg segment (k_step.inc has the reasons) */
             __shared__ int stash_[5][256];
             const int tid_ = threadIdx.x;
