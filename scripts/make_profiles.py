@@ -1,7 +1,7 @@
 """collect the rocprofv3 outputs of the round's measurement run (gpurun_out/r1_*) into profiles/"""
 import csv, glob, collections, json, shutil, sys
 from pathlib import Path
-R = sys.argv[1] if len(sys.argv) > 1 else "r1"
+R = sys.argv[1] if len(sys.argv) > 1 else "r3"
 root = Path(__file__).resolve().parent.parent
 out = root / "profiles"; out.mkdir(exist_ok=True)
 G = root / "gpurun_out"
@@ -95,6 +95,71 @@ if ring.exists():
                       f"{a['config']['host_enqueue_us_per_step']:.1f} µs per step (one C call for all {a['steps']} steps)."]
     except Exception as e:
         lines += ["", f"(bench lines missing: {e})"]
+# ---- steady state of the bench line from the per-dispatch kernel trace: the launches bench.py times are dispatches
+# [warmup, warmup + steps) of k_step; the --stats average also holds the ramp-up launches and the instrumented pass behind them
+import statistics
+bj = json.loads([l for l in open(out / f"{R}_bench.json") if l.startswith("{")][0])
+W_, K_ = bj["warmup"], bj["steps"]
+tr = pick(f"{R}_stats", "kernel_trace.csv", "k_step")
+ks = sorted((r for r in csv.DictReader(open(tr)) if "k_step<" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in ks]
+steady = dur[W_:W_ + K_]
+st = {"kernel": ks[0]["Kernel_Name"].split("(")[0], "dispatches_all": len(dur), "mean_all_ms": sum(dur) / len(dur),
+      "steady_window": [W_, W_ + K_], "mean_steady_ms": sum(steady) / len(steady), "min_steady_ms": min(steady),
+      "median_steady_ms": statistics.median(steady), "max_steady_ms": max(steady),
+      "algorithmic_bytes_per_launch": 64 * NP, "frac_of_8TBps_from_steady_mean": 64 * NP / (sum(steady) / len(steady) * 1e-3) / 8e12,
+      "bench_line_avg_launch_ms": bj["roofline"]["avg_launch_ms"], "bench_line_frac": bj["roofline"]["frac"]}
+json.dump(st, open(out / f"{R}_bench_kernel_steady.json", "w"), indent=1)
+shutil.copy(tr, out / f"{R}_bench_kernel_trace.csv")
+lines += ["", f"## Steady state of the bench line (`profiles/{R}_bench_kernel_trace.csv`, `{R}_bench_kernel_steady.json`)", "",
+          f"`rocprofv3 --kernel-trace` of the same command: {len(dur)} `k_step` dispatches (warm-up, the {K_} timed ones, the instrumented pass behind them); all-dispatch mean",
+          f"{st['mean_all_ms']:.4f} ms (what `--stats` prints); dispatches [{W_}, {W_ + K_}) — the timed region — mean **{st['mean_steady_ms']:.4f}** / min {st['min_steady_ms']:.4f} / median {st['median_steady_ms']:.4f} ms",
+          f"⇒ 64 B × {NP} ÷ {st['mean_steady_ms']:.4f} ms ÷ 8 TB/s = **{st['frac_of_8TBps_from_steady_mean']:.4f}**; the bench line of the same collection says",
+          f"{bj['roofline']['avg_launch_ms']:.4f} ms (one HIP event pair around the timed region) and frac {bj['roofline']['frac']:.4f}."]
+
+# ---- the default solver's kernels
+for tag, title in (("pmc_sq_auto", "AutoTsit5(Rosenbrock23()), winds (10,10)"), ("pmc_sq_auto_generic", "AutoTsit5(Rosenbrock23()), winds (10,3)")):
+    try:
+        a, na = agg(f"{R}_{tag}")
+        pd = per_dispatch(f"{R}_{tag}", "SQ_INSTS_VALU")
+    except SystemExit:
+        continue
+    for k, sct in a.items():
+        if k.startswith("k_step"):
+            busy = sct["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sct["GRBM_GUI_ACTIVE"] / 8)
+            lines += ["", f"## `{k}` — {title}", "",
+                      f"{na[k]} dispatches; VALU instructions per wave, dispatch by dispatch: {pd[k]}; VALU busy {busy:.2f}; wave lifetime "
+                      f"{4 * sct['SQ_WAVE_CYCLES'] / sct['SQ_WAVES']:.0f} cycles, of which waiting on memory / LDS / scalar loads {4 * sct['SQ_WAIT_INST_ANY'] / sct['SQ_WAVES']:.0f}."]
+            res[k + " " + title] = {"valu_busy": busy, "valu_insts_per_wave_steady": pd[k][-1]}
+
+# ---- BASELINE config 5
+try:
+    shutil.copy(G / f"{R}_cfg5_profile.jsonl", out / f"{R}_cfg5_profile.jsonl")
+    shutil.copy(pick(f"{R}_cfg5_stats", "kernel_stats.csv", "k_step"), out / f"{R}_cfg5_kernel_stats.csv")
+    a, na = agg(f"{R}_cfg5_pmc_sq"); f5, _ = agg(f"{R}_cfg5_pmc_fetch"); w5, _ = agg(f"{R}_cfg5_pmc_write")
+    prof = [json.loads(l) for l in open(out / f"{R}_cfg5_profile.jsonl") if l.startswith("{")]
+    lines += ["", "## BASELINE config 5 (2048², growing / decaying winds × cos(3t/(3600·2π)), 20-minute steps, default solver, device lattice)", "",
+              f"`scripts/cfg5_profile.py` (`profiles/{R}_cfg5_profile.jsonl`, `{R}_cfg5_kernel_stats.csv`):", ""]
+    for q in prof:
+        if "run" in q:
+            lines.append(f"* {q['run']}: {q['ms_per_step']:.3f} ms/step, `k_step` mean {q['k_step_ms']['mean']:.3f} / median {q['k_step_ms']['median']:.3f} ms, "
+                         f"{q['particles_on_per_step']:.0f} particles on, {q['rhs_per_particle_step']:.1f} RHS per particle-step, {q['rhs_per_kernel_s']:.3g} RHS/s (kernel time), "
+                         f"lane efficiency Σ attempts ÷ Σ 64 × wave maximum = **{q['lane_efficiency']:.3f}**, max reach {q['max_reach']}")
+        else:
+            lines.append(f"* config 5 runs at **{q['cfg5_rhs_per_kernel_s_over_box']:.2f}** of the homogeneous box's RHS throughput (kernel time; {q['cfg5_rhs_per_s_over_box']:.2f} by wall clock)")
+    lines += ["", "| kernel | dispatches | VALU insts / wave | VALU busy | HBM read (2×FETCH) | HBM written | bytes / node |", "|---|---|---|---|---|---|---|"]
+    N5 = 2048 * 2048
+    for k, sct in a.items():
+        if k.startswith("k_step") or k.startswith("k_wind_sample"):
+            busy = sct["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sct["GRBM_GUI_ACTIVE"] / 8)
+            rd = 2 * f5[k]["FETCH_SIZE"] * 1024; wb = w5[k]["WRITE_SIZE"] * 1024
+            lines.append(f"| `{k}` | {na[k]} | {sct['SQ_INSTS_VALU'] / sct['SQ_WAVES']:.0f} | {busy:.2f} | {rd / 1e9:.3f} GB | {wb / 1e9:.3f} GB | {(rd + wb) / N5:.0f} |")
+except (SystemExit, FileNotFoundError) as e:
+    lines += ["", f"(config 5 profile missing: {e})"]
+
 (out / f"{R}_pmc_summary.md").write_text("\n".join(lines) + "\n")
-json.dump({"config": {"n": 4096, "winds": [10.0, 10.0]}, "dominant": dom, "kernels": res}, open(out / f"{R}_pmc_traffic.json", "w"), indent=1)
+sys.path.insert(0, str(root))
+import bench as _bench
+json.dump({"config": {"n": 4096, "winds": [10.0, 10.0]}, "kernel_stamp": _bench.kernel_stamp(), "kernel_sources": list(_bench.KERNEL_SOURCES),
+           "dominant": dom, "kernels": res}, open(out / f"{R}_pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines))
