@@ -348,10 +348,14 @@ __device__ __forceinline__ unsigned int xcd_block(void)
     return (n % 8u == 0u) ? l : b;
 }
 
+/* every kernel of the step families is launched with 256 threads per workgroup (StepLaunch.block, __launch_bounds__(256)) */
+#define PICLES_BLOCK 256
 /* local rows [r0, r0+n0) ∪ [r1, r1+n1) -> particle index */
 __device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r1, int n1, long long &t)
 {
-    long long tid = (long long)xcd_block() * blockDim.x + threadIdx.x;
+    /* (PICLES_BLOCK, not blockDim.x: the run-time value is a load from the dispatch packet, a memory round trip at the head of
+     * every wave's chain of dependent prologue loads — the phase clock put that chain at a third of a wave's life) */
+    long long tid = (long long)xcd_block() * PICLES_BLOCK + threadIdx.x;
     long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
     if (tid >= na + nb) return false;
     t = (tid < na) ? (long long)r0 * G.Nx + tid : (long long)r1 * G.Nx + (tid - na);

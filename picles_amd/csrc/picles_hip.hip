@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) k_scatter(KParams P, GridP G, Arrays A, i
                                                    double clock, double DT)
 {
     if (REMESH) pm_device_init();
-    long long t = (long long)xcd_block() * blockDim.x + threadIdx.x;
+    long long t = (long long)xcd_block() * PICLES_BLOCK + threadIdx.x;
     unsigned int reseeds = 0;
     const bool active = t < A.n;
     if (active) {

@@ -143,7 +143,12 @@ __device__ __forceinline__ double *pm_lds_tab(void)
 }
 __device__ __forceinline__ void pm_device_init(void)
 {
-    for (int i = threadIdx.x; i < PM_EXP_N; i += blockDim.x) pm_lds_tab()[i] = PM_EXP_TAB_C[i];
+    /* 256 threads per workgroup in every kernel that calls this (not blockDim.x: that is a load from the dispatch packet, and with
+     * the trip count known both table loads are in flight together): two entries per thread */
+    static_assert(PM_EXP_N == 512, "two table entries per thread of a 256-thread workgroup");
+    const double t0 = PM_EXP_TAB_C[threadIdx.x], t1 = PM_EXP_TAB_C[threadIdx.x + 256];
+    pm_lds_tab()[threadIdx.x] = t0;
+    pm_lds_tab()[threadIdx.x + 256] = t1;
     __syncthreads();
 }
 #define PM_EXP_TAB(j) (pm_lds_tab()[(j)])
