@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
     dp_device_init(TSIT ? 1 : 0);
     pm_device_init();
     long long t = 0;
-    bool active = rows_index(G, r0, n0, r1, n1, t);
+    bool active = rows_index(G, r0, n0, r1, n1, t, xcd_block());
     if (active) rmap_clear_ahead(A, t);      /* every node of the rows, stepped or not: the clear must reach every tile */
     unsigned char pf = active ? A.pflags[t] : 0;
     active = active && (pf & PF_STEPPED);

@@ -64,8 +64,18 @@ struct Arrays {
      * 1 in the calm half).  Five buffers of ntile ints rotating with the reach counters above (same three indices). */
     int ntile;
     int *rmap;
+    /* cost-ordered dispatch of the fused step (whole-grid launches).  Every workgroup files its 256-node block at the end of a
+     * step: blocks that integrated or re-seeded somebody from the front of a permutation, blocks with nothing to do from the back.
+     * The next launch hands the blocks out in that order — busy ones first, calm ones last — when at least an eighth of them was
+     * calm.  The hardware deals workgroups to its shader engines in turn and waits for the engine whose turn it is: with waves of
+     * 10 and 45 µs mixed four-and-four along every row (BASELINE config 5) the wave slots were 1.8 of 3 filled on average; with
+     * like next to like the deal runs smoothly.  Five rotating buffers of (busy count, calm count, order[nblk]) ints, indices as
+     * for the reach counters; ord_on = 0: natural order (the previous step built no permutation: row ranges, stand-alone advance). */
+    int ord_on, nblk;
+    int *ord;
     long long n;             /* Nx * ny_loc */
 };
+__device__ __forceinline__ int *order_buf(const Arrays &A, int which) { return A.ord + (size_t)which * (size_t)(2 + A.nblk); }
 
 __device__ __forceinline__ int *reach_counters(const Arrays &A) { return (int *)(A.cnt + NSLOTS); }
 
@@ -331,7 +341,12 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S,
             atomicMax(mr_out, m_reach);
             atomicMax(mr + 5, m_reach);                                      /* the running maximum can only rise when this one does */
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) mr[(A.mr_idx >> 8) & 15] = 0;       /* nobody reads or writes it during this step */
+        if (blockIdx.x == 0 && threadIdx.x == 0) {       /* nobody reads or writes these during this step */
+            mr[(A.mr_idx >> 8) & 15] = 0;
+            mr[8 + ((A.mr_idx >> 8) & 15)] = 0;
+        }
+        /* "this step had waves with nothing to do" (order_wanted below): a wave that advanced nobody and re-seeded nobody says so */
+        if (!b_adv && !s_res && mr[8 + ((A.mr_idx >> 4) & 15)] == 0) mr[8 + ((A.mr_idx >> 4) & 15)] = 1;
     }
 }
 
@@ -350,12 +365,51 @@ __device__ __forceinline__ unsigned int xcd_block(void)
 
 /* every kernel of the step families is launched with 256 threads per workgroup (StepLaunch.block, __launch_bounds__(256)) */
 #define PICLES_BLOCK 256
-/* local rows [r0, r0+n0) ∪ [r1, r1+n1) -> particle index */
-__device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r1, int n1, long long &t)
+/* the 256-node block of this workgroup: the permutation the previous step filed, or the XCD-banded natural order.  In two halves:
+ * the counts are asked for BEFORE the kernel's first barrier (a scalar load the compiler would not move above it) and looked at
+ * behind it, so their round trip overlaps the table set-up */
+__device__ __forceinline__ long long order_counts(const Arrays &A)
+{
+    return A.ord_on ? *(const long long *)order_buf(A, A.mr_idx & 15) : 0ll;
+}
+__device__ __forceinline__ unsigned int ordered_block(const Arrays &A, long long counts)
+{
+    if (A.ord_on) {
+        const int busy = (int)(counts & 0xffffffffll), calm = (int)(counts >> 32);
+        if (busy + calm == A.nblk && (int)gridDim.x == A.nblk && 8 * calm >= A.nblk)
+            return (unsigned int)order_buf(A, A.mr_idx & 15)[2 + blockIdx.x];
+    }
+    return xcd_block();
+}
+/* file this block for the next step.  No barrier: every wave signs off in an LDS word (order_sign_init() zeroes it ahead of the
+ * kernel's first barrier) and the last one to do so — it sees the other three, and whether any of them was busy — files the block */
+__device__ __forceinline__ int *order_sign(void)
+{
+    __shared__ int sign_;
+    return &sign_;
+}
+__device__ __forceinline__ void order_sign_init(void) { if (threadIdx.x == 0) *order_sign() = 0; }
+/* filing costs every workgroup an atomic with a returned value at the very end of its life (+1-2 % on the homogeneous box,
+ * measured): it is done only while the runs are mixed — the previous step had calm waves (a word beside the reach counter) */
+__device__ __forceinline__ bool order_wanted(const Arrays &A) { return reach_counters(A)[8 + (A.mr_idx & 15)] != 0; }
+__device__ __forceinline__ void order_file(const Arrays &A, unsigned int lblock, bool wave_busy)
+{
+    if ((threadIdx.x & 63) != 0) return;
+    const int v = atomicAdd(order_sign(), 1 + (wave_busy ? 256 : 0));
+    if ((v & 255) != (int)(PICLES_BLOCK / 64) - 1) return;
+    const bool busy = wave_busy || (v >> 8) != 0;
+    int *const wb = order_buf(A, (A.mr_idx >> 4) & 15);
+    const int pos = busy ? atomicAdd(wb, 1) : A.nblk - 1 - atomicAdd(wb + 1, 1);
+    if (pos >= 0 && pos < A.nblk) wb[2 + pos] = (int)lblock;
+    if (blockIdx.x == 0) { int *const cb = order_buf(A, (A.mr_idx >> 8) & 15); cb[0] = 0; cb[1] = 0; }
+}
+
+/* local rows [r0, r0+n0) ∪ [r1, r1+n1) -> particle index; lblock: the 256-node block the workgroup works on */
+__device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r1, int n1, long long &t, unsigned int lblock)
 {
     /* (PICLES_BLOCK, not blockDim.x: the run-time value is a load from the dispatch packet, a memory round trip at the head of
      * every wave's chain of dependent prologue loads — the phase clock put that chain at a third of a wave's life) */
-    long long tid = (long long)xcd_block() * PICLES_BLOCK + threadIdx.x;
+    long long tid = (long long)lblock * PICLES_BLOCK + threadIdx.x;
     long long na = (long long)n0 * G.Nx, nb = (long long)n1 * G.Nx;
     if (tid >= na + nb) return false;
     t = (tid < na) ? (long long)r0 * G.Nx + tid : (long long)r1 * G.Nx + (tid - na);

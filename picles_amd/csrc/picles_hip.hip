@@ -445,6 +445,7 @@ struct picles_ctx {
     double *d_wgu = nullptr, *d_wgv = nullptr;
     double wind_t1 = 0.0;          /* time level currently held in (u1, v1) */
     bool wind_t1_valid = false;
+    bool ord_valid = false;        /* the previous step was a whole-grid fused launch: it filed a complete dispatch order (kernels.h: Arrays::ord) */
     double *um_buf = nullptr, *vm_buf = nullptr;   /* mid-window wind level (picles_set_winds3); A.um / A.vm point here while in use */
     bool ext_streams = false;      /* a caller-provided stream has been used: order across streams with device syncs */
     bool ring_orders = false;      /* inside picles_slab_run_steps: the ring orders its streams against the context stream with events */
@@ -691,6 +692,13 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
         CK(hipMalloc(&c->rec_buf[k], rec_bytes(c)));
         CK(hipMemset(c->rec_buf[k], 0, rec_bytes(c)));
     }
+    A.nblk = (int)((n + 255) / 256);
+    A.ord_on = 0;
+    A.ord = nullptr;
+    if (G.single_slab) {
+        CK(hipMalloc(&A.ord, (size_t)5 * (2 + A.nblk) * sizeof(int)));
+        CK(hipMemset(A.ord, 0, (size_t)5 * (2 + A.nblk) * sizeof(int)));
+    }
     A.ntile = (int)((n + 63) / 64);
     CK(hipMalloc(&A.rmap, (size_t)5 * A.ntile * sizeof(int)));      /* local reach map, five rotating buffers (kernels.h: Arrays::rmap) */
     CK(hipMemset(A.rmap, 0, (size_t)5 * A.ntile * sizeof(int)));
@@ -719,6 +727,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
     if (c->um_buf) { hipFree(c->um_buf); hipFree(c->vm_buf); }
     hipFree(A.cnt); hipFree(A.rmap); hipFree(c->d_mask);
+    if (A.ord) hipFree(A.ord);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
     for (int k = 0; k < 2; k++) hipFree(c->rec_buf[k]);
 
@@ -904,6 +913,7 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
         if (rc) return rc;
     }
     c->pending = false;
+    c->ord_valid = false;
     c->cur = 0;
     c->mr_w = 0;
     for (int k = 0; k < 2; k++) {
@@ -912,7 +922,7 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
         if (k == 0) for (int q = 2; q < 5; q++) HIPCHK(c, hipMemsetAsync(c->mr_buf[q], 0, sizeof(int), c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->A.cnt, 0, NSLOTS * sizeof(DevCounters), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->mr_buf[0] + 5, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mr_buf[0] + 5, 0, 11 * sizeof(int), c->stream));      /* running maximum + the "calm waves" words (kernels.h: order_wanted) */
     HIPCHK(c, hipMemsetAsync(c->A.rmap, 0, (size_t)5 * c->A.ntile * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_seed, dim3(nblocks(c->A.n, 256)), dim3(256), 0, c->stream, c->P, c->G, arrays_for(c, 0, 0), c->d_mask, c->od.timestep);
     HIPCHK(c, hipGetLastError());
@@ -1002,6 +1012,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     long long nt = (long long)(n0 + n1) * c->G.Nx;
     if (nt == 0) return 0;
     if ((rc = step_prologue(c, s))) return rc;
+    c->ord_valid = false;        /* the stand-alone advance files no dispatch order */
     timing_begin(c, s, 0);
     {
         const KParams &P = c->P;
@@ -1046,6 +1057,17 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     Arrays A = arrays_for(c, c->cur ^ 1, c->cur);
     /* specialised variant: every physics switch on and n = 2 (all reference scripts) */
     bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
+    /* cost-ordered dispatch (kernels.h): whole-grid launches of a context that is not in slab mode file an order and follow the
+     * one the launch before them filed; any other launch in between breaks the chain (its counters are cleared on the way) */
+    const bool whole = c->A.ord && which == PICLES_ROWS_ALL && c->G.single_slab;
+    if (whole) {
+        if (!c->ord_valid) HIPCHK(c, hipMemsetAsync(c->A.ord, 0, (size_t)5 * (2 + c->A.nblk) * sizeof(int), s));
+        A.ord_on = c->ord_valid ? 1 : 0;
+        c->ord_valid = true;
+    } else {
+        A.ord = nullptr;            /* (this launch neither reads nor files an order) */
+        c->ord_valid = false;
+    }
     timing_begin(c, s, 0);
     {
         StepLaunch L = {dim3(nblocks(nt, 256)), dim3(256), s, &c->P, &c->G, &A, c->pend_t, c->pend_dt, c->clock, c->step_dt, r0, n0, r1, n1};

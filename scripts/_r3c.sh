@@ -1,3 +1,2 @@
-bash scripts/ab_libs.sh 2>&1
-run() { PICLES_HIP_LIB=$1 python bench.py --steps 200 --warmup 5 --no-cpu --no-secondary --no-events ${@:2} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4))"; }
-for lib in _b_var/*.so; do echo "256 noev $(basename $lib): $(run $PWD/$lib --grid-n 256) | $(run $PWD/$lib --grid-n 256) ;  1448: $(run $PWD/$lib --grid-n 1448)"; done
+for lib in _b_var/*.so; do echo "cfg5 $(basename $lib): $(PICLES_HIP_LIB=$PWD/$lib python scripts/cfg5_probe.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), round(d['advance_ms_per_launch'],3))")"; done
+bash scripts/ab_libs.sh 2>&1 | head -8

@@ -56,6 +56,7 @@ hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? h
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : fail(hipErrorOutOfMemory); }
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st)
 {
