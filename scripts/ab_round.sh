@@ -1,0 +1,7 @@
+#!/bin/bash
+# one same-box round over the variant libraries in _b_var/: default-solver lines, config 5, the general-physics kernels (dead band)
+run() { PICLES_HIP_LIB=$1 python bench.py --steps 20 --warmup 5 --no-cpu --no-secondary ${@:2} 2>>gpurun_out/ab_round.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['ms_per_step'],4), round(r['min_launch_ms'],4), round(r['median_launch_ms'],4))"; }
+for v in "--solver AutoTsit5" "--solver AutoTsit5 --winds 10,3" "--deadband 1e-9" "--deadband 1e-9 --solver Tsit5"; do
+  for lib in _b_var/*.so; do echo "[$v] $(basename $lib): $(run $PWD/$lib $v) | $(run $PWD/$lib $v)"; done
+done
+for lib in _b_var/*.so; do echo "cfg5 $(basename $lib): $(PICLES_HIP_LIB=$PWD/$lib python scripts/cfg5_probe.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), round(d['advance_ms_per_launch'],3))")"; done
