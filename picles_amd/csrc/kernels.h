@@ -377,13 +377,7 @@ __device__ __forceinline__ unsigned int ordered_block(const Arrays &A, long long
     if (A.ord_on) {
         const int busy = (int)(counts & 0xffffffffll), calm = (int)(counts >> 32);
         if (busy + calm == A.nblk && (int)gridDim.x == A.nblk && 8 * calm >= A.nblk)
-#ifdef PICLES_ORDER_REV      /* experiment: the whole permutation backwards (calm blocks first) */
-            return (unsigned int)order_buf(A, A.mr_idx & 15)[2 + ((int)A.nblk - 1 - (int)blockIdx.x)];
-#elif defined(PICLES_ORDER_LPT)      /* experiment: busy blocks in reverse order of completion (the longest-running ones first) */
-            return (unsigned int)order_buf(A, A.mr_idx & 15)[2 + ((int)blockIdx.x < busy ? busy - 1 - (int)blockIdx.x : (int)blockIdx.x)];
-#else
             return (unsigned int)order_buf(A, A.mr_idx & 15)[2 + blockIdx.x];
-#endif
     }
     return xcd_block();
 }
