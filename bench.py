@@ -327,7 +327,7 @@ def main():
                 "achieved_tflops": tflops,
                 "peak_tflops": FP64_PEAK_TFLOPS * world,
                 "frac": tflops / (FP64_PEAK_TFLOPS * world),
-                # from the committed PMC profile of this exact workload (profiles/r1_pmc_summary.md), null otherwise
+                # from the committed PMC profile of this exact workload (profiles/r3_pmc_traffic.json, quoted only while its kernel stamp matches the tree), null otherwise
                 "valu_issue_busy": valu_busy,
                 "valu_insts_per_wave": valu_per_wave,
             },
