@@ -216,6 +216,12 @@ int32_t picles_get_timing(picles_ctx *ctx, picles_timing *t);       /* syncs */
 /* per-launch device durations [ms] since picles_enable_timing(1): kind 0 = step / advance launches, 1 = scatter, 2 = remesh.
  * Copies up to cap values; returns the number of samples held (>= 0) or an error (< 0). */
 int32_t picles_get_timing_samples(picles_ctx *ctx, int32_t kind, double *out_ms, int32_t cap);
+/* Diagnostic: the dispatch order the latest whole-grid fused step filed for its successor (cost-ordered dispatch):
+ * out[0] = workgroups that did work, out[1] = workgroups with nothing to do, out[2 ...] = the logical 256-node blocks in the order
+ * they will be dealt (busy ones from the front, calm ones from the back).  Copies min(cap, 2 + n) ints; returns n = the number of
+ * workgroups of that launch when a complete order was filed (out[0] + out[1] == n), 0 when none was (the run is not mixed, or the
+ * context is a slab), < 0 on error.  Syncs and completes a pending fused step, like every getter.  No counterpart in the reference. */
+int32_t picles_get_dispatch_order(picles_ctx *ctx, int32_t *out, int32_t cap);
 int32_t picles_sync(picles_ctx *ctx);
 
 /* ---- split phases for the slab-partitioned (multi-GPU) step -------------------

@@ -134,6 +134,7 @@ SYMBOLS = {
     "picles_enable_timing": (C.c_int32, [_VP, C.c_int32]),
     "picles_get_timing": (C.c_int32, [_VP, C.POINTER(PiclesTiming)]),
     "picles_get_timing_samples": (C.c_int32, [_VP, C.c_int32, c_double_p, C.c_int32]),
+    "picles_get_dispatch_order": (C.c_int32, [_VP, C.POINTER(C.c_int32), C.c_int32]),
     "picles_sync": (C.c_int32, [_VP]),
     "picles_begin_step": (C.c_int32, [_VP, C.c_double, C.c_int32]),
     "picles_advance_rows": (C.c_int32, [_VP, C.c_int32, _VP]),

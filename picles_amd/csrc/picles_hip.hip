@@ -1354,6 +1354,22 @@ PX_EXPORT int32_t picles_get_counters(picles_ctx *c, picles_counters *out)
     return 0;
 }
 
+PX_EXPORT int32_t picles_get_dispatch_order(picles_ctx *c, int32_t *out, int32_t cap)
+{
+    if (!c) return -1;
+    if (cap < 0 || (cap > 0 && !out)) return fail(c, -2, "picles_get_dispatch_order: bad buffer");
+    if (!c->A.ord || !c->ord_valid) return 0;
+    const int n = c->A.nblk;
+    std::vector<int> h((size_t)2 + n);
+    /* the buffer the latest step wrote: the counters rotate at the end of a step */
+    int rc = d2h(c, h.data(), c->A.ord + (size_t)((c->mr_w + 4) % 5) * (size_t)(2 + n), h.size() * sizeof(int));
+    if (rc) return rc;
+    if (h[0] + h[1] != n) return 0;
+    const int m = cap < 2 + n ? cap : 2 + n;
+    for (int k = 0; k < m; k++) out[k] = h[k];
+    return n;
+}
+
 PX_EXPORT int32_t picles_reset_counters(picles_ctx *c)
 {
     if (!c) return -1;

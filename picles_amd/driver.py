@@ -331,6 +331,19 @@ class HipModel:
         n = self.lib.picles_get_timing_samples(self.h, kind, K.dptr(out), n)
         return out[:max(n, 0)]
 
+    def get_dispatch_order(self):
+        """(busy, calm, order) filed by the latest whole-grid fused step for its successor, or None when no complete order exists"""
+        n = self.lib.picles_get_dispatch_order(self.h, None, 0)
+        if n < 0:
+            self._ck(n, "picles_get_dispatch_order")
+        if n == 0:
+            return None
+        out = np.empty(2 + n, dtype=np.int32)
+        n2 = self.lib.picles_get_dispatch_order(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size)
+        if n2 != n:
+            return None
+        return int(out[0]), int(out[1]), out[2:].copy()
+
     def get_timing(self):
         t = K.PiclesTiming()
         self._ck(self.lib.picles_get_timing(self.h, C.byref(t)), "picles_get_timing")

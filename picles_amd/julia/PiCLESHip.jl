@@ -258,6 +258,19 @@ function counters(model::WaveGrowth2DHIP)
 end
 
 """
+diagnostic: `(busy, calm, order)` — the dispatch order the latest whole-grid fused step filed for its successor (the cost-ordered
+dispatch of mixed calm / busy runs), or `nothing` when the run is not mixed
+"""
+function dispatch_order(model::WaveGrowth2DHIP)
+    n = ccall((:picles_get_dispatch_order, libpicles), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32), model.ctx, C_NULL, 0)
+    n < 0 && check(model.ctx, n, "picles_get_dispatch_order")
+    n == 0 && return nothing
+    out = Vector{Int32}(undef, 2 + n)
+    ccall((:picles_get_dispatch_order, libpicles), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32), model.ctx, out, length(out)) == n || return nothing
+    return (Int(out[1]), Int(out[2]), out[3:end])
+end
+
+"""
 particles that could not be scattered: farther than the reach cap of the pull scatter (64 cells per model step for a
 whole-grid context — a deliberate limit of this implementation, INTEGRATION.md; the reference wraps at any distance) or
 with a non-finite position (the reference throws in `Int(floor(NaN))`).  They are counted, never silently lost.

@@ -126,7 +126,14 @@ void run_program(Rng &R, int Nx, int Ny, int j0, int j1, int halo, bool whole)
             expect_ok(c, picles_get_particles(c, R.coin() ? z.p : nullptr, R.coin() ? on.p : nullptr, R.coin() ? bd.p : nullptr, R.coin() ? st.p : nullptr), "get_particles");
             if (R.coin()) expect_ok(c, picles_set_particles(c, z.p, R.coin() ? on.p : nullptr), "set_particles");
         } break;
-        case 7: { picles_counters cn; expect_ok(c, picles_get_counters(c, &cn), "get_counters"); if (R.coin()) expect_ok(c, picles_reset_counters(c), "reset_counters"); } break;
+        case 7: {
+            picles_counters cn; expect_ok(c, picles_get_counters(c, &cn), "get_counters"); if (R.coin()) expect_ok(c, picles_reset_counters(c), "reset_counters");
+            int n = picles_get_dispatch_order(c, nullptr, 0);       /* (the fake device runs no kernels: no order is ever complete) */
+            if (n < 0) { fprintf(stderr, "dispatch_order rc=%d\n", n); exit(3); }
+            int cap = R.in(0, 6);
+            Buf<int32_t> ord((size_t)cap);
+            if (picles_get_dispatch_order(c, cap ? ord.p : nullptr, cap) < 0) { fprintf(stderr, "dispatch_order(cap) failed\n"); exit(3); }
+        } break;
         case 8: expect_ok(c, picles_enable_timing(c, R.coin()), "enable_timing"); break;
         case 9: {
             picles_timing t; expect_ok(c, picles_get_timing(c, &t), "get_timing");

@@ -1,0 +1,56 @@
+"""The cost-ordered dispatch of the fused step (kernels.h: Arrays::ord) is a speed matter only — results are bitwise equal with
+any order, which the parity suites hold — so nothing else would notice if it silently never engaged.  This test looks at the
+order itself through the diagnostic getter: on a run whose domain is half calm the fused steps file a complete permutation of
+their workgroups, busy ones in front of calm ones; on the homogeneous box they file nothing."""
+import numpy as np
+import pytest
+
+from picles_amd import configs
+from picles_amd.models import WaveGrowth2D
+from picles_amd.simulations import Simulation, initialize_simulation
+from picles_amd.timesteppers import time_step
+from picles_amd.wind_emulator import wind_interpolator
+
+pytestmark = pytest.mark.gpu
+
+
+def _lattice_model(n, steps):
+    cfg = configs.growing_decaying_winds(n=n)
+    g = cfg.model["grid"]
+    x = g.data.x[:, 0]; y = np.array([0.0, g.data.y[0, -1]]); t = np.arange(0.0, (steps + 4) * cfg.Δt, cfg.Δt)
+    X, Y, T = np.meshgrid(x, y, t, indexing="ij")
+    w = wind_interpolator(dict(x=x, y=y, t=t, u=cfg.model["winds"].u(X, Y, T), v=cfg.model["winds"].v(X, Y, T)))
+    cfg.model["winds"] = w; cfg.model["ODEsys"].u, cfg.model["ODEsys"].v = w.u, w.v
+    m = WaveGrowth2D(**cfg.model)
+    initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    return m, cfg
+
+
+def test_half_calm_run_files_a_permutation_with_busy_blocks_first():
+    n, steps = 512, 6
+    m, cfg = _lattice_model(n, steps)
+    for _ in range(steps):
+        time_step(m, cfg.Δt, zero_first=True)
+    got = m.backend.get_dispatch_order()
+    assert got is not None, "no dispatch order was filed on a half-calm run"
+    busy, calm, order = got
+    nblk = n * n // 256
+    assert busy + calm == nblk and busy > 0 and 8 * calm >= nblk, (busy, calm)
+    assert np.array_equal(np.sort(order), np.arange(nblk))
+    # a workgroup owns 256 consecutive nodes of the index space (x fastest): with 512 nodes per row, block 2j is the left half of
+    # row j — winds of 0.1 m/s below x0 = L/2, nobody on — and block 2j + 1 the right half, where the ramp starts
+    on = m.backend.get_particles()[1]                                   # [x, y]
+    has_on = np.array([on[(b % 2) * 256:(b % 2 + 1) * 256, b // 2].any() for b in range(nblk)])
+    assert not has_on[0::2].any() and has_on[1::2].all()
+    # (the first and the last row are grid boundary: their particles are not stepped, whatever the wind)
+    assert set(order[:busy].tolist()) == set(range(3, nblk - 2, 2))
+    assert set(order[busy:].tolist()) == set(range(0, nblk, 2)) | {1, nblk - 1}
+
+
+def test_homogeneous_box_files_nothing():
+    cfg = configs.box4096(n=256)
+    m = WaveGrowth2D(**cfg.model)
+    initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    for _ in range(5):
+        time_step(m, cfg.Δt, zero_first=True)
+    assert m.backend.get_dispatch_order() is None
