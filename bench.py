@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -137,6 +138,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (generic wind direction, default solver)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="GPU clock conditioning before the warm-up: about this many milliseconds of the same model steps, then a "
+                         "re-seed (the model is back at t = 0 in its initial state), then the W warm-up and the K timed steps as "
+                         "always.  A GPU that has idled needs tens of milliseconds of load before its waves run at full speed "
+                         "(measured: a 4096 x 512 slab 0.341 -> 0.313 ms per step; DESIGN.md section 7.0): 5 warm-up steps of a "
+                         "third of a millisecond each end long before that.  0 = off.")
     ap.add_argument("--deadband", type=float, default=0.0,
                     help="opt-in picles_phys.dir_deadband (0 = reference-exact RHS; the headline number uses 0)")
     ap.add_argument("--solver", default="DP5", choices=["DP5", "Tsit5", "AutoTsit5"],
@@ -217,6 +224,19 @@ def main():
                           ring_of_one=args.ring_of_one,
                           native_ring=True if args.native_ring else (None if (args.backend == "nccl" and not args.python_loop) else False))
         model.seed()
+        # clock conditioning (--prewarm-ms): the same steps, un-timed, in cycles of at most 40 (the scatter reach of the box stays 1 that
+        # long: no halo grows, nothing overflows), each followed by a re-seed — after the last one the model is exactly where
+        # model.seed() left it.  The number of steps is a function of the grid alone: every rank runs the same.
+        pre_steps = 0
+        if args.prewarm_ms > 0:
+            per_rank = args.n * args.n / world
+            pre_steps = int(min(4000, max(5, math.ceil(args.prewarm_ms * 1e-3 * 6.5e9 / per_rank))))
+            left = pre_steps
+            while left > 0:
+                model.run_steps(cfg.Δt, min(left, 40), flags)
+                left -= 40
+                model.seed()
+        model.prewarm_steps = pre_steps
         model.run_steps(cfg.Δt, W_, flags)
         model.backend.reset_counters()
         # one GPU: the K launches are back to back on one stream — ONE event pair around them (mean launch = region / K);
@@ -346,6 +366,9 @@ def main():
             out["roofline"]["median_launch_ms"] = float(np.median(samples))
         out["state_check"] = state_check
         out["config"]["host_enqueue_us_per_step"] = 1e6 * model.host_enqueue_s / Ksteps
+        out["config"]["clock_prewarm"] = {"target_ms": args.prewarm_ms, "untimed_steps": model.prewarm_steps,
+                                          "note": "un-timed steps of the same model followed by a re-seed, before the W warm-up steps "
+                                                  "(GPU clock conditioning; 0 = off: --prewarm-ms 0)"}
         out["config"]["step_loop"] = ("native: picles_slab_run_steps (RCCL send/recv issued from C)" if model.native else
                                       ("native: picles_run_steps" if (world == 1 and not args.atomic and model.ex is None) else
                                        "python: one C call per step" + ("" if world == 1 else ", torch.distributed P2P")))

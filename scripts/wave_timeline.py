@@ -1,0 +1,71 @@
+"""debug: per-wave timeline of the LAST fused launch of a homogeneous-box run (library built with -DPICLES_WAVE_LOG, which makes
+k_step write (start, after the pull, end, hardware id) of every wave into the unused MovieState planes; s_memrealtime, 10 ns ticks).
+    PICLES_HIP_LIB=_b_var/wavelog.so python scripts/wave_timeline.py [n] [solver]"""
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+from picles_amd import configs
+from picles_amd.models import WaveGrowth2D
+from picles_amd.simulations import Simulation, initialize_simulation
+from picles_amd.timesteppers import time_step
+
+import time
+from picles_amd.grids import TwoDCartesianGridMesh
+shape = sys.argv[1] if len(sys.argv) > 1 else "1448"
+nx, ny = (int(v) for v in shape.split("x")) if "x" in shape else (int(shape), int(shape))
+n = nx
+cfg = configs.box4096(n=nx)
+if ny != nx:      # a y-slab of the periodic box as one whole-grid context (the per-rank shape of a multi-GPU run)
+    cfg.model["grid"] = TwoDCartesianGridMesh(0.0, 2000.0 * (nx - 1), nx, 0.0, 2000.0 * (ny - 1), ny, periodic_boundary=(True, True))
+if len(sys.argv) > 2:
+    cfg.model["ODEsets"].solver = sys.argv[2]
+m = WaveGrowth2D(**cfg.model)
+initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+NSTEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+time_step(m, cfg.Δt, zero_first=True)
+PREWARM_MS = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+if PREWARM_MS > 0:         # keep the GPU busy with the same kernels on a twin model first: does the shader clock need time to come up?
+    m2 = WaveGrowth2D(**cfg.model)
+    initialize_simulation(Simulation(m2, Δt=cfg.Δt, stop_time=1.0))
+    time_step(m2, cfg.Δt, zero_first=True)
+    m2.backend.sync(); m.backend.sync()
+    t_ = time.perf_counter()
+    while 1e3 * (time.perf_counter() - t_) < PREWARM_MS:
+        m2.backend.run_steps(cfg.Δt, 10)
+        m2.backend.sync()
+m.backend.run_steps(cfg.Δt, NSTEPS - 1)
+m.backend.sync()
+raw = m.backend.get_movie_state().ravel(order="F").view(np.uint64)          # the planes as they lie in memory
+t_ = time.perf_counter()
+m.backend.run_steps(cfg.Δt, 20)                      # the native loop, as bench.py times it (the log above is of the launch before it)
+m.backend.sync()
+native_ms = 1e3 * (time.perf_counter() - t_) / 20
+nw = (nx * ny + 63) // 64
+b = raw[:4 * nw].reshape(nw, 4).astype(np.int64)
+st, pl, en, hw = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+ok = (st > 0) & (en > st)
+st, pl, en, hw = st[ok], pl[ok], en[ok], hw[ok]
+t0 = st.min()
+st, pl, en = (st - t0) * 0.01, (pl - t0) * 0.01, (en - t0) * 0.01          # µs
+span = en.max()
+dur = en - st
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = (hw >> 32) & 15
+key = ((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd)
+nsimd = len(np.unique(key))
+edges = np.linspace(0.0, span, 41)
+occ = [float(((st < hi) & (en > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
+order = np.argsort(st)
+q = [order[int(f * (len(order) - 1))] for f in (0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0)]
+out = {"shape": [nx, ny], "steps": NSTEPS, "prewarm_ms": PREWARM_MS, "native_ms_per_step": native_ms, "waves": int(ok.sum()), "simds_seen": int(nsimd), "span_us": float(span),
+       "wave_us": {"mean": float(dur.mean()), "min": float(dur.min()), "median": float(np.median(dur)), "max": float(dur.max())},
+       "pull_us_mean": float((pl - st).mean()),
+       "slots_filled_mean": float(dur.sum() / span / max(nsimd, 1)),
+       "occupancy_per_simd_over_time_40_bins": [round(o / max(nsimd, 1), 2) for o in occ],
+       "start_us_quantiles": [round(float(st[i]), 1) for i in q],
+       "duration_by_start_decile_us": [round(float(dur[order[int(k * len(order) / 10):int((k + 1) * len(order) / 10)]].mean()), 1) for k in range(10)],
+       "pull_by_start_decile_us": [round(float((pl - st)[order[int(k * len(order) / 10):int((k + 1) * len(order) / 10)]].mean()), 1) for k in range(10)],
+       "last_wave_end_minus_90pct_end_us": float(span - np.percentile(en, 90))}
+print(json.dumps(out))
