@@ -72,6 +72,22 @@ def test_live_bench_prints_one_json_line():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--ring-of-one"]])
+def test_clock_conditioning_leaves_the_timed_steps_untouched(extra):
+    """bench.py's --prewarm-ms phase (un-timed steps of the same model, then a re-seed) must hand the W warm-up and the K timed steps
+    exactly the model a fresh seed gives: the same steps are timed, the same work is counted, the state after them agrees to the bit"""
+    def run(ms):
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--grid-n", "256", "--no-cpu",
+                              "--no-secondary", "--prewarm-ms", str(ms)] + extra, check=True, capture_output=True, text=True).stdout
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    a, b = run(0), run(5)
+    assert a["config"]["clock_prewarm"]["untimed_steps"] == 0 and b["config"]["clock_prewarm"]["untimed_steps"] > 40      # more than one cycle
+    assert a["state_check"] == b["state_check"]
+    assert a["fp64"]["rhs_evals_per_particle_step"] == b["fp64"]["rhs_evals_per_particle_step"]
+    assert a["steps"] == b["steps"] == 4 and a["warmup"] == b["warmup"] == 2
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_ring_of_one_bench_prints_one_json_line():
     """the N > 1 data path of bench.py (native slab ring: the library's own RCCL communicator, edge / interior streams, halo
