@@ -1603,7 +1603,7 @@ struct SlabRing {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, prev = -1, next = -1;      /* -1: no neighbour on that side (open y axis) */
     hipStream_t sE = nullptr, sM = nullptr;
-    hipEvent_t evE = nullptr, evM = nullptr;
+    hipEvent_t evE = nullptr, evM = nullptr, evEd = nullptr;      /* evEd: this step's edge launch alone (without the exchange behind it) */
     unsigned long long steps = 0, exchanged_bytes = 0;
 };
 
@@ -1640,6 +1640,7 @@ PX_EXPORT int32_t picles_slab_comm_destroy(picles_ctx *c)
     if (R->comm) R->api->CommDestroy(R->comm);
     if (R->evE) hipEventDestroy(R->evE);
     if (R->evM) hipEventDestroy(R->evM);
+    if (R->evEd) hipEventDestroy(R->evEd);
     if (R->sE) hipStreamDestroy(R->sE);
     if (R->sM) hipStreamDestroy(R->sM);
     delete R;
@@ -1679,6 +1680,7 @@ PX_EXPORT int32_t picles_slab_comm_init(picles_ctx *c, const void *id128, int32_
     HIPCHK(c, hipStreamCreateWithFlags(&R->sM, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&R->evE, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&R->evM, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&R->evEd, hipEventDisableTiming));
     return 0;
 }
 
@@ -1744,11 +1746,20 @@ PX_EXPORT int32_t picles_slab_run_steps(picles_ctx *c, double dt, int32_t n_step
         HIPCHK(c, hipStreamWaitEvent(R->sE, R->evM, 0));
         int rc = (fused == 0) ? picles_step_rows(c, PICLES_ROWS_EDGE, R->sE) : picles_advance_rows(c, PICLES_ROWS_EDGE, R->sE);
         if (rc) return rc;
+        if (fused == 0) HIPCHK(c, hipEventRecord(R->evEd, R->sE));
         if ((rc = ring_exchange(c, R, R->sE))) return rc;
         rc = (fused == 0) ? picles_step_rows(c, PICLES_ROWS_INTERIOR, R->sM) : picles_advance_rows(c, PICLES_ROWS_INTERIOR, R->sM);
         if (rc) return rc;
-        HIPCHK(c, hipEventRecord(R->evE, R->sE));
-        HIPCHK(c, hipStreamWaitEvent(R->sM, R->evE, 0));      /* stream M waits for the edge rows and the halo */
+        if (fused == 0) {
+            /* fused steps: what runs next on M is the next step's interior launch.  Its pull reads own rows only — the records the
+             * edge launch of THIS step wrote among them — never the ghost rows: it waits for the edge kernel, not for the exchange
+             * behind it.  The communication is off the interior's critical path altogether; only the next edge launch (same
+             * stream as the exchange) consumes the received rows. */
+            HIPCHK(c, hipStreamWaitEvent(R->sM, R->evEd, 0));
+        } else {
+            HIPCHK(c, hipEventRecord(R->evE, R->sE));
+            HIPCHK(c, hipStreamWaitEvent(R->sM, R->evE, 0));      /* the scatter on M reads the edge rows and the received halo */
+        }
         c->edge_pending = false;
         rc = (fused == 0) ? picles_end_fused_step(c) : picles_scatter_remesh(c, R->sM);
         if (rc) return rc;

@@ -103,9 +103,13 @@ W_, K_ = bj["warmup"], bj["steps"]
 tr = pick(f"{R}_stats", "kernel_trace.csv", "k_step")
 ks = sorted((r for r in csv.DictReader(open(tr)) if "k_step<" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in ks]
-steady = dur[W_:W_ + K_]
+# the profiled command (`bench.py --steps K --warmup W --no-cpu --no-secondary`) ends with the instrumented pass of 3 + min(K, 10) launches
+# behind the K timed ones; whatever runs before them (clock conditioning, warm-up: their first steps are k_advance, not k_step) sits in front
+S_ = (3 + min(K_, 10)) if "launch_samples" in bj["roofline"] else 0
+lo_ = len(dur) - S_ - K_
+steady = dur[lo_:lo_ + K_]
 st = {"kernel": ks[0]["Kernel_Name"].split("(")[0], "dispatches_all": len(dur), "mean_all_ms": sum(dur) / len(dur),
-      "steady_window": [W_, W_ + K_], "mean_steady_ms": sum(steady) / len(steady), "min_steady_ms": min(steady),
+      "steady_window": [lo_, lo_ + K_], "mean_steady_ms": sum(steady) / len(steady), "min_steady_ms": min(steady),
       "median_steady_ms": statistics.median(steady), "max_steady_ms": max(steady),
       "algorithmic_bytes_per_launch": 64 * NP, "frac_of_8TBps_from_steady_mean": 64 * NP / (sum(steady) / len(steady) * 1e-3) / 8e12,
       "bench_line_avg_launch_ms": bj["roofline"]["avg_launch_ms"], "bench_line_frac": bj["roofline"]["frac"]}
@@ -113,7 +117,7 @@ json.dump(st, open(out / f"{R}_bench_kernel_steady.json", "w"), indent=1)
 shutil.copy(tr, out / f"{R}_bench_kernel_trace.csv")
 lines += ["", f"## Steady state of the bench line (`profiles/{R}_bench_kernel_trace.csv`, `{R}_bench_kernel_steady.json`)", "",
           f"`rocprofv3 --kernel-trace` of the same command: {len(dur)} `k_step` dispatches (warm-up, the {K_} timed ones, the instrumented pass behind them); all-dispatch mean",
-          f"{st['mean_all_ms']:.4f} ms (what `--stats` prints); dispatches [{W_}, {W_ + K_}) — the timed region — mean **{st['mean_steady_ms']:.4f}** / min {st['min_steady_ms']:.4f} / median {st['median_steady_ms']:.4f} ms",
+          f"{st['mean_all_ms']:.4f} ms (what `--stats` prints); dispatches [{lo_}, {lo_ + K_}) — the timed region — mean **{st['mean_steady_ms']:.4f}** / min {st['min_steady_ms']:.4f} / median {st['median_steady_ms']:.4f} ms",
           f"⇒ 64 B × {NP} ÷ {st['mean_steady_ms']:.4f} ms ÷ 8 TB/s = **{st['frac_of_8TBps_from_steady_mean']:.4f}**; the bench line of the same collection says",
           f"{bj['roofline']['avg_launch_ms']:.4f} ms (one HIP event pair around the timed region) and frac {bj['roofline']['frac']:.4f}."]
 
