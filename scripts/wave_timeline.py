@@ -15,13 +15,22 @@ from picles_amd.timesteppers import time_step
 import time
 from picles_amd.grids import TwoDCartesianGridMesh
 shape = sys.argv[1] if len(sys.argv) > 1 else "1448"
-nx, ny = (int(v) for v in shape.split("x")) if "x" in shape else (int(shape), int(shape))
+nx, ny = (2048, 2048) if shape == "cfg5" else ((int(v) for v in shape.split("x")) if "x" in shape else (int(shape), int(shape)))
 n = nx
 cfg = configs.box4096(n=nx)
 if ny != nx:      # a y-slab of the periodic box as one whole-grid context (the per-rank shape of a multi-GPU run)
     cfg.model["grid"] = TwoDCartesianGridMesh(0.0, 2000.0 * (nx - 1), nx, 0.0, 2000.0 * (ny - 1), ny, periodic_boundary=(True, True))
 if len(sys.argv) > 2:
     cfg.model["ODEsets"].solver = sys.argv[2]
+if shape == "cfg5":          # BASELINE config 5 with its forcing as a device lattice (scripts/cfg5_profile.py)
+    from picles_amd.wind_emulator import wind_interpolator
+    cfg = configs.growing_decaying_winds(n=2048)
+    nx = ny = n = 2048
+    g_ = cfg.model["grid"]
+    x_ = g_.data.x[:, 0]; y_ = np.array([0.0, g_.data.y[0, -1]]); t_ax = np.arange(0.0, 120 * cfg.Δt, cfg.Δt)
+    X_, Y_, T_ = np.meshgrid(x_, y_, t_ax, indexing="ij")
+    w_ = wind_interpolator(dict(x=x_, y=y_, t=t_ax, u=cfg.model["winds"].u(X_, Y_, T_), v=cfg.model["winds"].v(X_, Y_, T_)))
+    cfg.model["winds"] = w_; cfg.model["ODEsys"].u, cfg.model["ODEsys"].v = w_.u, w_.v
 m = WaveGrowth2D(**cfg.model)
 initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
 NSTEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 12
@@ -68,4 +77,15 @@ out = {"shape": [nx, ny], "steps": NSTEPS, "prewarm_ms": PREWARM_MS, "native_ms_
        "duration_by_start_decile_us": [round(float(dur[order[int(k * len(order) / 10):int((k + 1) * len(order) / 10)]].mean()), 1) for k in range(10)],
        "pull_by_start_decile_us": [round(float((pl - st)[order[int(k * len(order) / 10):int((k + 1) * len(order) / 10)]].mean()), 1) for k in range(10)],
        "last_wave_end_minus_90pct_end_us": float(span - np.percentile(en, 90))}
+busy = dur > 0.5 * (dur.max() + dur.min()) if shape == "cfg5" else np.ones_like(dur, dtype=bool)
+if shape == "cfg5":
+    occ_b = [float(((st[busy] < hi) & (en[busy] > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
+    occ_c = [float(((st[~busy] < hi) & (en[~busy] > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
+    # exact time-averaged residency per SIMD slot: sum of overlaps with each bin / bin width
+    def resid(sel):
+        w = edges[1] - edges[0]
+        return [round(float(np.clip(np.minimum(en[sel], hi) - np.maximum(st[sel], lo), 0, None).sum() / w / max(nsimd, 1)), 2) for lo, hi in zip(edges[:-1], edges[1:])]
+    out.update({"busy_waves": int(busy.sum()), "calm_waves": int((~busy).sum()), "busy_wave_us_mean": float(dur[busy].mean()), "calm_wave_us_mean": float(dur[~busy].mean()),
+                "busy_pull_us_mean": float((pl - st)[busy].mean()), "resident_busy_waves_per_simd_40_bins": resid(busy), "resident_calm_waves_per_simd_40_bins": resid(~busy),
+                "busy_duration_quantiles_us": [round(float(np.percentile(dur[busy], q)), 1) for q in (5, 25, 50, 75, 95, 100)]})
 print(json.dumps(out))
