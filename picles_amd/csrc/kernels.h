@@ -337,7 +337,8 @@ __device__ __forceinline__ void flush_stats(const Arrays &A, const StepStats &S,
         if (m_att) atomicAdd(&c->wslots, 64ull * (unsigned long long)m_att);
         /* one address for the whole grid: only waves that would raise it touch it */
         int *const mr = reach_counters(A), *const mr_out = mr + ((A.mr_idx >> 4) & 15);
-        if (m_reach > __hip_atomic_load(mr_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        /* (a wave without a record has nothing to raise: it does not look — the load would sit at the very end of its life) */
+        if (m_reach > 0 && m_reach > __hip_atomic_load(mr_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             atomicMax(mr_out, m_reach);
             atomicMax(mr + 5, m_reach);                                      /* the running maximum can only rise when this one does */
         }
@@ -372,12 +373,17 @@ __device__ __forceinline__ long long order_counts(const Arrays &A)
 {
     return A.ord_on ? *(const long long *)order_buf(A, A.mr_idx & 15) : 0ll;
 }
-__device__ __forceinline__ unsigned int ordered_block(const Arrays &A, long long counts)
+/* ... and this workgroup's entry of the permutation with them, before it is known whether the permutation is complete (its address
+ * depends on nothing but the block index): one round trip instead of two in the chain counts -> entry -> block -> every other load */
+__device__ __forceinline__ int order_entry(const Arrays &A)
+{
+    return (A.ord_on && (int)blockIdx.x < A.nblk) ? order_buf(A, A.mr_idx & 15)[2 + blockIdx.x] : 0;
+}
+__device__ __forceinline__ unsigned int ordered_block(const Arrays &A, long long counts, int entry)
 {
     if (A.ord_on) {
         const int busy = (int)(counts & 0xffffffffll), calm = (int)(counts >> 32);
-        if (busy + calm == A.nblk && (int)gridDim.x == A.nblk && 8 * calm >= A.nblk)
-            return (unsigned int)order_buf(A, A.mr_idx & 15)[2 + blockIdx.x];
+        if (busy + calm == A.nblk && (int)gridDim.x == A.nblk && 8 * calm >= A.nblk) return (unsigned int)entry;
     }
     return xcd_block();
 }
@@ -675,6 +681,7 @@ __device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i,
                                          double &s0, double &s1, double &s2)
 {
     const int W = 2 * R + 1;
+    if (R == 0) return;       /* the reach map says that nobody around left a record (pull_reach_local): the node value stays 0 */
     if (G.tripolar && jl + G.j_begin >= G.Ny - R) pull_node_tripolar(G, A, i, jl, R, s0, s1, s2);
     else if ((G.periodic_x && W > G.Nx) || (G.periodic_y && W > G.Ny)) pull_node_aliased(G, A, i, jl, R, s0, s1, s2);
     else if (R == 1) pull_node<1>(G, A, i, jl, 1, s0, s1, s2);
@@ -688,13 +695,17 @@ __device__ __forceinline__ void pull_any(const GridP &G, const Arrays &A, int i,
  * covers halo_rows for the rows that can receive from a neighbour's particles (the edge rows: the neighbour's reach is not
  * known here), and for its interior rows — fed by own particles only — again the measured reach, which is what keeps the
  * common case at 9 candidates per node instead of (2 halo_rows + 1)².  Any reach >= the true one gives the same bits. */
-__device__ __forceinline__ int pull_reach(const GridP &G, const Arrays &A, int jl)
+/* the counter itself is asked for at the very start of the kernel (pull_reach_early: its address depends on the arguments alone,
+ * and the compiler does not move a load above the first barrier by itself): one link less in the chain of dependent round trips
+ * reach -> reach map -> candidates that a wave with nothing else to do spends its life in */
+__device__ __forceinline__ int pull_reach_early(const Arrays &A) { return reach_counters(A)[A.mr_idx & 15]; }
+__device__ __forceinline__ int pull_reach(const GridP &G, const Arrays &A, int jl, int m)
 {
     if (G.Rp > 0 && (jl < G.R || jl >= G.ny_loc - G.R)) return G.Rp;
-    int m = reach_counters(A)[A.mr_idx & 15];
     if (m < 1) m = 1;
     return (G.Rp > 0 && m > G.Rp) ? G.Rp : m;
 }
+__device__ __forceinline__ int pull_reach(const GridP &G, const Arrays &A, int jl) { return pull_reach(G, A, jl, pull_reach_early(A)); }
 
 
 /* every tile's first particle clears the tile's entry in the map two steps ahead (nobody reads or writes that buffer during this
@@ -719,7 +730,7 @@ __device__ __forceinline__ int pull_reach_local(const GridP &G, const Arrays &A,
     if (Rg >= 2 && Rg <= 31 && !edge_row && i - Rg >= 0 && i + Rg < G.Nx && jl - Rg >= 0 && jl + Rg < G.ny_loc &&
         j - Rg >= 0 && j + Rg < G.Ny) {
         const int *const rm = A.rmap + (size_t)(A.mr_idx & 15) * (size_t)A.ntile;
-        int m = 1;
+        int m = 0;                        /* 0: no particle of any tile in the window left a record — nothing can land here */
         long long t0 = (long long)(jl - Rg) * G.Nx + (i - Rg);
         for (int dj = -Rg; dj <= Rg; dj++, t0 += G.Nx) {                           /* 2 Rg + 1 <= 63 columns: at most two tiles per row */
             const int a = rm[t0 >> 6], b = rm[(t0 + 2 * Rg) >> 6];
@@ -728,8 +739,8 @@ __device__ __forceinline__ int pull_reach_local(const GridP &G, const Arrays &A,
         R = min(m, Rg);
     }
     if (Rg < 2) return Rg;
-    int m = 1;
-    while (__ballot(R > m)) m++;          /* <= Rg - 1 rounds */
+    int m = 0;
+    while (__ballot(R > m)) m++;          /* <= Rg rounds */
     return m;
 }
 
