@@ -219,8 +219,8 @@ int32_t picles_get_timing_samples(picles_ctx *ctx, int32_t kind, double *out_ms,
 /* Diagnostic: the dispatch order the latest whole-grid fused step filed for its successor (cost-ordered dispatch):
  * out[0] = workgroups that did work, out[1] = workgroups with nothing to do, out[2 ...] = the logical 256-node blocks in the order
  * they will be dealt (busy ones from the front, calm ones from the back).  Copies min(cap, 2 + n) ints; returns n = the number of
- * workgroups of that launch when a complete order was filed (out[0] + out[1] == n), 0 when none was (the run is not mixed, or the
- * context is a slab), < 0 on error.  Syncs and completes a pending fused step, like every getter.  No counterpart in the reference. */
+ * workgroups of that launch when a complete order was filed (out[0] + out[1] == n), 0 when none was (the run is not mixed; a slab reports
+ * the order of the launch over its interior rows), < 0 on error.  Syncs and completes a pending fused step, like every getter.  No counterpart in the reference. */
 int32_t picles_get_dispatch_order(picles_ctx *ctx, int32_t *out, int32_t cap);
 int32_t picles_sync(picles_ctx *ctx);
 

@@ -445,7 +445,8 @@ struct picles_ctx {
     double *d_wgu = nullptr, *d_wgv = nullptr;
     double wind_t1 = 0.0;          /* time level currently held in (u1, v1) */
     bool wind_t1_valid = false;
-    bool ord_valid = false;        /* the previous step was a whole-grid fused launch: it filed a complete dispatch order (kernels.h: Arrays::ord) */
+    bool ord_valid = false;        /* the previous fused step filed a dispatch order (kernels.h: Arrays::ord) with ... */
+    int ord_nblk = 0;              /* ... this many workgroups: the whole grid, or the interior rows of a slab */
     double *um_buf = nullptr, *vm_buf = nullptr;   /* mid-window wind level (picles_set_winds3); A.um / A.vm point here while in use */
     bool ext_streams = false;      /* a caller-provided stream has been used: order across streams with device syncs */
     bool ring_orders = false;      /* inside picles_slab_run_steps: the ring orders its streams against the context stream with events */
@@ -695,10 +696,8 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     A.nblk = (int)((n + 255) / 256);
     A.ord_on = 0;
     A.ord = nullptr;
-    if (G.single_slab) {
-        CK(hipMalloc(&A.ord, (size_t)5 * (2 + A.nblk) * sizeof(int)));
-        CK(hipMemset(A.ord, 0, (size_t)5 * (2 + A.nblk) * sizeof(int)));
-    }
+    CK(hipMalloc(&A.ord, (size_t)5 * (2 + A.nblk) * sizeof(int)));      /* (a slab orders the launch over its interior rows: fewer workgroups) */
+    CK(hipMemset(A.ord, 0, (size_t)5 * (2 + A.nblk) * sizeof(int)));
     A.ntile = (int)((n + 63) / 64);
     CK(hipMalloc(&A.rmap, (size_t)5 * A.ntile * sizeof(int)));      /* local reach map, five rotating buffers (kernels.h: Arrays::rmap) */
     CK(hipMemset(A.rmap, 0, (size_t)5 * A.ntile * sizeof(int)));
@@ -1057,16 +1056,21 @@ static int launch_step_rows(picles_ctx *c, int which, hipStream_t s)
     Arrays A = arrays_for(c, c->cur ^ 1, c->cur);
     /* specialised variant: every physics switch on and n = 2 (all reference scripts) */
     bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
-    /* cost-ordered dispatch (kernels.h): whole-grid launches of a context that is not in slab mode file an order and follow the
-     * one the launch before them filed; any other launch in between breaks the chain (its counters are cleared on the way) */
-    const bool whole = c->A.ord && which == PICLES_ROWS_ALL && c->G.single_slab;
-    if (whole) {
-        if (!c->ord_valid) HIPCHK(c, hipMemsetAsync(c->A.ord, 0, (size_t)5 * (2 + c->A.nblk) * sizeof(int), s));
-        A.ord_on = c->ord_valid ? 1 : 0;
+    /* cost-ordered dispatch (kernels.h): the launch that covers (nearly) everything — the whole grid of a plain context, the interior
+     * rows of a slab — files an order over ITS workgroups and follows the one its predecessor of the same shape filed.  The edge
+     * launch of a slab (a handful of workgroups, on the other stream) neither reads nor files one and leaves the chain alone; a
+     * stand-alone advance, a re-seed or a change of the launch shape (halo resize) breaks it (its counters are cleared on the way). */
+    const bool orders = c->A.ord && (c->G.single_slab ? which == PICLES_ROWS_ALL : which == PICLES_ROWS_INTERIOR);
+    if (orders) {
+        A.nblk = (int)nblocks(nt, 256);
+        const bool follows = c->ord_valid && c->ord_nblk == A.nblk;
+        if (!follows) HIPCHK(c, hipMemsetAsync(c->A.ord, 0, (size_t)5 * (2 + c->A.nblk) * sizeof(int), s));
+        A.ord_on = follows ? 1 : 0;
         c->ord_valid = true;
+        c->ord_nblk = A.nblk;
     } else {
         A.ord = nullptr;            /* (this launch neither reads nor files an order) */
-        c->ord_valid = false;
+        if (c->G.single_slab || which != PICLES_ROWS_EDGE) c->ord_valid = false;
     }
     timing_begin(c, s, 0);
     {
@@ -1359,7 +1363,7 @@ PX_EXPORT int32_t picles_get_dispatch_order(picles_ctx *c, int32_t *out, int32_t
     if (!c) return -1;
     if (cap < 0 || (cap > 0 && !out)) return fail(c, -2, "picles_get_dispatch_order: bad buffer");
     if (!c->A.ord || !c->ord_valid) return 0;
-    const int n = c->A.nblk;
+    const int n = c->ord_nblk;
     std::vector<int> h((size_t)2 + n);
     /* the buffer the latest step wrote: the counters rotate at the end of a step */
     int rc = d2h(c, h.data(), c->A.ord + (size_t)((c->mr_w + 4) % 5) * (size_t)(2 + n), h.size() * sizeof(int));

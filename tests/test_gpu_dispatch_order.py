@@ -54,3 +54,41 @@ def test_homogeneous_box_files_nothing():
     for _ in range(5):
         time_step(m, cfg.Δt, zero_first=True)
     assert m.backend.get_dispatch_order() is None
+
+
+def test_slab_orders_its_interior_launch_and_stays_bitwise():
+    """a slab (here: the native ring of one, context in slab mode) files and follows an order over the workgroups of its INTERIOR
+    launch — the edge launch leaves the chain alone — and the result is that of the plain context, bit for bit"""
+    from helpers import assert_bitwise, make_model
+    from picles_amd.parallel import SlabModel
+    n, steps, halo = 512, 7, 2
+
+    def cfg_():
+        cfg = configs.growing_decaying_winds(n=n)
+        u0, v0 = cfg.model["winds"].u, cfg.model["winds"].v
+        # the ramp of config 5 without its time factor: time-constant winds, so that ring and plain context both take the fused static path;
+        # periodic in y so that the ring of one has something to exchange
+        cfg.model["winds"].u = lambda x, y, t: u0(x, y, 0.0 * t)
+        cfg.model["winds"].v = lambda x, y, t: v0(x, y, 0.0 * t)
+        cfg.model["ODEsys"].u, cfg.model["ODEsys"].v = cfg.model["winds"].u, cfg.model["winds"].v
+        cfg.model["winds_static"] = True
+        from picles_amd.grids import TwoDCartesianGridMesh
+        g = cfg.model["grid"]
+        L = float(g.data.x[-1, 0])
+        cfg.model["grid"] = TwoDCartesianGridMesh(0.0, L, n, 0.0, L, n, periodic_boundary=(False, True))
+        return cfg
+    cfg = cfg_()
+    ring = SlabModel(cfg.model, 0, 1, device=0, halo_rows=halo, ring_of_one=True)
+    ring.seed()
+    ring.run_steps(cfg.Δt, steps)
+    got = ring.backend.get_dispatch_order()
+    assert got is not None, "the interior launch of the slab filed no order"
+    busy, calm, order = got
+    nblk = (n - 2 * halo) * n // 256                     # the interior rows only
+    assert busy + calm == nblk and busy > 0 and 8 * calm >= nblk, (busy, calm, nblk)
+    assert np.array_equal(np.sort(order), np.arange(nblk))
+    cfg2 = cfg_()
+    plain = make_model(cfg2, "hip")
+    initialize_simulation(Simulation(plain, Δt=cfg2.Δt, stop_time=1.0))
+    plain.backend.run_steps(cfg2.Δt, steps)
+    assert_bitwise(ring.get_state(), plain.State, "State")
