@@ -539,10 +539,60 @@ __device__ __forceinline__ void pull_node_aliased(const GridP &G, const Arrays &
     }
 }
 
-/* sum of the contributions to node (i, j); RT > 0: reach known at compile time (fully unrolled:
- * all candidate codes are loaded before any is inspected), RT == 0: runtime reach R.
+/* sum of the contributions to node (i, j); RT > 0: reach known at compile time (RT = 1, 2: the two-phase window above; RT = 3, 4: a row
+ * at a time, unrolled along the row), RT == 0: runtime reach R.
  * Record elements are addressed with 32-bit offsets from one base pointer (the host falls back to
  * a single-plane-per-call layout check: (ny_loc + 2R) * 6 * Nx < 2^31 elements). */
+/* The (2R+1)² window of an interior node in two phases.  Phase 1: the codes of ALL candidates are loaded before any is inspected
+ * (one memory round trip); each lane notes which candidates land on its node, and on which corner, in three bit masks.  Phase 2: the
+ * lane walks its matches in candidate order, four at a time, and issues the value loads of all four back to back before the first
+ * is consumed — one more round trip, where a branch per matching candidate took one each (a node has four matches under a
+ * uniform flow: the pull was a chain of 1 + 4 dependent round trips at reach 1, 5 + 4 at reach 2, and at reach 2 the waves spent
+ * so long in it that the issue port ran 89 % busy instead of 97 %).  Sums are formed in candidate order: the same bits.  The
+ * addresses come from an opaque copy of the base (hoisted out of the loop over the particle lists they spill by the hundred). */
+template <int R, int DJ0 = -R, int NJ = 2 * R + 1>      /* rows DJ0 .. DJ0 + NJ - 1 of the window: a band of at most 32 candidates */
+__device__ __forceinline__ void pull_window_2p(const double *__restrict__ rec, unsigned int base, unsigned int pl, unsigned int rowlen,
+                                               int grp, double &s0, double &s1, double &s2)
+{
+    constexpr int W = 2 * R + 1, NC = W * NJ;
+    static_assert(NC <= 32, "one bit per candidate");
+    __asm__ volatile("" : "+v"(base));
+    unsigned int m = 0u, ax = 0u, ay = 0u;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int di = c % W - R, dj = c / W + DJ0;
+        const int d = (int)rec[base + (unsigned int)(dj * (int)rowlen + di) + 5u * pl] - (grp + 4 * (REC_BIAS - 1 - di) + 4 * 4096 * (REC_BIAS - 1 - dj));
+        m |= ((d & ~(4 | 16384)) == 0 ? 1u : 0u) << c;
+        ax |= ((d & 4) ? 0u : 1u) << c;
+        ay |= ((d & 16384) ? 0u : 1u) << c;
+    }
+    while (__ballot(m != 0u)) {
+        double e[4], mx[4], my[4], wx[4], wy[4];
+        bool on[4], hx[4], hy[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            on[k] = (m != 0u);
+            const int c = on[k] ? __builtin_ctz(m) : 0;
+            m &= m - 1u;
+            hx[k] = (ax >> c) & 1u; hy[k] = (ay >> c) & 1u;
+            const unsigned int off = base + (unsigned int)((c / W + DJ0) * (int)rowlen + (c % W - R));
+            e[k] = mx[k] = my[k] = wx[k] = wy[k] = 0.0;
+            if (on[k]) {
+                wx[k] = rec[off + 3u * pl]; wy[k] = rec[off + 4u * pl];
+                e[k] = rec[off]; mx[k] = rec[off + pl]; my[k] = rec[off + 2u * pl];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (on[k]) {
+                const double w = (hx[k] ? wx[k] : 1.0 - wx[k]) * (hy[k] ? wy[k] : 1.0 - wy[k]);
+                s0 += w * e[k];
+                s1 += w * mx[k];
+                s2 += w * my[k];
+            }
+        }
+    }
+}
 template <int RT>
 __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i, int jl, int Rdyn,
                                           double &s0, double &s1, double &s2)
@@ -557,16 +607,13 @@ __device__ __forceinline__ void pull_node(const GridP &G, const Arrays &A, int i
     if (interior) {
         const unsigned int base = (unsigned int)(jl + RO) * rowlen + (unsigned int)i;
         for (int grp = 1; grp <= G.ngroups; grp++) {
-            if constexpr (RT == 1) {
-#pragma unroll
-                for (int dj = -1; dj <= 1; dj++) {
-#pragma unroll
-                    for (int di = -1; di <= 1; di++)
-                        pull_candidate(rec, base + (unsigned int)(dj * (int)rowlen + di), pl, di, dj, grp, true, s0, s1, s2);
-                }
+            if constexpr (RT == 1 || RT == 2) {
+                /* reach 1 and 2 — the first steps of a run and the developed sea.  (Bands of rows for reach 3 and 4 were built too:
+                 * the compiler answered with 124 instead of 30 lane moves inside the RK loop of the time-varying default-solver
+                 * kernel, which is the one that meets such reaches; they keep the row loop below.) */
+                pull_window_2p<RT>(rec, base, pl, rowlen, grp, s0, s1, s2);
             } else {
-                /* wider reach: one row of candidates at a time keeps the register footprint of the
-                 * fused step kernel at two waves per SIMD */
+                /* wider reach: one row of candidates at a time */
 #pragma unroll 1
                 for (int dj = -R; dj <= R; dj++) {
                     const unsigned int rb = base + (unsigned int)(dj * (int)rowlen);

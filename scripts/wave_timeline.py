@@ -77,6 +77,18 @@ out = {"shape": [nx, ny], "steps": NSTEPS, "prewarm_ms": PREWARM_MS, "native_ms_
        "duration_by_start_decile_us": [round(float(dur[order[int(k * len(order) / 10):int((k + 1) * len(order) / 10)]].mean()), 1) for k in range(10)],
        "pull_by_start_decile_us": [round(float((pl - st)[order[int(k * len(order) / 10):int((k + 1) * len(order) / 10)]].mean()), 1) for k in range(10)],
        "last_wave_end_minus_90pct_end_us": float(span - np.percentile(en, 90))}
+# the four waves of a workgroup: how far apart they end (a slot is handed on only when the whole workgroup is done)
+blk = (b[:, 3][ok] >> 40).astype(np.int64)
+o_ = np.argsort(blk, kind="stable")
+bs, es, ss = blk[o_], en[o_], st[o_]
+first = np.flatnonzero(np.r_[True, bs[1:] != bs[:-1]])
+cnt = np.diff(np.r_[first, bs.size])
+full = cnt == 4
+e4 = np.stack([es[first[full] + k] for k in range(4)], axis=1)
+s4 = np.stack([ss[first[full] + k] for k in range(4)], axis=1)
+out["workgroup_end_spread_us"] = {"mean": float((e4.max(1) - e4.min(1)).mean()), "p90": float(np.percentile(e4.max(1) - e4.min(1), 90))}
+out["workgroup_start_spread_us"] = {"mean": float((s4.max(1) - s4.min(1)).mean())}
+out["rk_us_mean"] = float((en - pl).mean())
 busy = dur > 0.5 * (dur.max() + dur.min()) if shape == "cfg5" else np.ones_like(dur, dtype=bool)
 if shape == "cfg5":
     occ_b = [float(((st[busy] < hi) & (en[busy] > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
