@@ -111,6 +111,40 @@ def test_user_particles_propagation_only_blob():
     assert Sg[..., 0].sum() == pytest.approx(np.exp(z[..., 0])[on == 1].sum(), rel=1e-13)   # conservation
 
 
+@pytest.mark.parametrize("ring", [1, 2])
+def test_convergent_particles_many_matches_per_node(ring):
+    """the two-phase pull walks a lane's matching candidates four at a time: here every particle within `ring` cells of node (10, 10)
+    moves towards it and lands on one of its cells — 9 (reach 1) and 25 (reach 2) sources on ONE node, against the oracle's sequential push"""
+    def fn():
+        cfg = configs.bench06_box(n=24, dx=1000.0)
+        s = cfg.model["ODEsys"]
+        s.input = s.dissipation = s.peak_shift = s.direction = False
+        return cfg
+    g, o = _pair(fn)
+    z = np.zeros((24, 24, 5)); z[..., 0] = -3.0; z[..., 1] = 1e-3
+    on = np.zeros((24, 24), dtype=np.uint8)
+    rng = np.random.default_rng(11 + ring)
+    n_src = 0
+    for di in range(-ring, ring + 1):
+        for dj in range(-ring, ring + 1):
+            i, j = 10 + di, 10 + dj
+            on[i, j] = 1
+            # cells moved in 600 s on a 1000 m mesh: 0.6 c; aim at the cell next to the centre on the particle's own side
+            tx = -(abs(di) - 0.5) * np.sign(di) if di else rng.uniform(-0.4, 0.4)
+            ty = -(abs(dj) - 0.5) * np.sign(dj) if dj else rng.uniform(-0.4, 0.4)
+            z[i, j, :3] = [rng.uniform(-3, 0), tx / 0.6, ty / 0.6]
+            n_src += 1
+    for m in (g, o):
+        m.backend.set_winds(np.zeros((24, 24)), np.zeros((24, 24)))
+        m.backend.set_particles(z, on)
+        m.backend.zero_state()
+        m.backend.advance(600.0)
+    Sg, So = g.backend.get_state(), o.backend.get_state()
+    assert_bitwise(Sg, So, "State")
+    assert Sg[10, 10, 0] > 0 and Sg[..., 0].sum() == pytest.approx(np.exp(z[..., 0])[on == 1].sum(), rel=1e-13)
+    assert g.backend.get_counters()["max_reach"] == ring and n_src == (2 * ring + 1) ** 2
+
+
 def test_nan_and_clamp_guards():
     fn = lambda: configs.example_00_minimal(n=17, L=32e3)
     g, o = _pair(fn)
