@@ -566,6 +566,39 @@ __device__ __forceinline__ void pull_window_2p(const double *__restrict__ rec, u
         ax |= ((d & 4) ? 0u : 1u) << c;
         ay |= ((d & 16384) ? 0u : 1u) << c;
     }
+    /* under a locally uniform flow every lane of the wave has the same set of matching candidates: the walk is then done once, on
+     * scalars (which candidate, its offset), and only the corner bits and the values stay per lane */
+    const unsigned int m0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)m);
+    if (!__ballot(m != m0)) {
+        unsigned int mu = m0;
+        while (mu != 0u) {
+            double e[4], mx[4], my[4], wx[4], wy[4];
+            bool on[4], hx[4], hy[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                on[k] = (mu != 0u);
+                const int c = on[k] ? __builtin_ctz(mu) : 0;
+                mu &= mu - 1u;
+                hx[k] = (ax >> c) & 1u; hy[k] = (ay >> c) & 1u;
+                const unsigned int off = base + (unsigned int)((c / W + DJ0) * (int)rowlen + (c % W - R));
+                e[k] = mx[k] = my[k] = wx[k] = wy[k] = 0.0;
+                if (on[k]) {
+                    wx[k] = rec[off + 3u * pl]; wy[k] = rec[off + 4u * pl];
+                    e[k] = rec[off]; mx[k] = rec[off + pl]; my[k] = rec[off + 2u * pl];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (on[k]) {
+                    const double w = (hx[k] ? wx[k] : 1.0 - wx[k]) * (hy[k] ? wy[k] : 1.0 - wy[k]);
+                    s0 += w * e[k];
+                    s1 += w * mx[k];
+                    s2 += w * my[k];
+                }
+            }
+        }
+        return;
+    }
     while (__ballot(m != 0u)) {
         double e[4], mx[4], my[4], wx[4], wy[4];
         bool on[4], hx[4], hy[4];
