@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PICLES_ABI_VERSION 3
+#define PICLES_ABI_VERSION 4
 
 /* ---- grid: TwoDCartesianGridStatistics + mesh mask (Grids/CartesianGrid.jl:26-101,
  *      Grids/mask_utils.jl:38-55) ------------------------------------------------ */
@@ -148,6 +148,15 @@ int32_t picles_set_winds(picles_ctx *ctx, const double *u0, const double *v0, do
 int32_t picles_set_winds3(picles_ctx *ctx, const double *u0, const double *v0, double t0,
                           const double *um, const double *vm,
                           const double *u1, const double *v1, double t1);
+/* Three levels with the middle one at a KNOT of a gridded wind, t0 < tk < t1: the RHS evaluates the two straight segments
+ * (t0,u0)-(tk,uk)-(t1,u1).  This is the exact form, inside one model step, of wind_interpolator's
+ * linear_interpolation((x,y,t), u) (Utils/WindEmulator.jl:18-43) when one time knot of the lattice falls inside the step: the
+ * reference's RHS evaluates that interpolant at every stage time (particle_waves_v5.jl:494-495), so the solver sees the kink.
+ * A window without an interior knot is picles_set_winds; one with two or more is not representable (take model steps no longer
+ * than the lattice's time spacing). */
+int32_t picles_set_winds_knot(picles_ctx *ctx, const double *u0, const double *v0, double t0,
+                              const double *uk, const double *vk, double tk,
+                              const double *u1, const double *v1, double t1);
 
 /* Non-Cartesian meshes (SphericalGrid.jl:207-240, spherical_grid_corrections.jl:3-21): per-node
  * projection kernel M = diag(m11, m22) of the propagation terms (particle_waves_v5.jl:536) and the
@@ -157,13 +166,31 @@ int32_t picles_set_metric(picles_ctx *ctx, const double *m11, const double *m22,
 
 /* Gridded wind forcing (Utils/WindEmulator.jl:18-43 wind_interpolator =
  * Interpolations.linear_interpolation((x,y,t), u; extrapolation_bc = Periodic())): u,v on a regular
- * (x,y,t) lattice [nx*ny*nt], x fastest.  The library keeps the lattice in HBM and samples the two
+ * (x,y,t) lattice [nx*ny*nt], x fastest.  The library keeps the lattice in HBM and samples the
  * time levels of every step at the mesh nodes itself (tri-linear, periodic continuation), so no
  * wind data crosses PCIe inside the time loop.  mesh_x0/mesh_y0: coordinates of node (0,0).
- * Replaces picles_set_winds until picles_set_winds is called again. */
+ * Replaces picles_set_winds until picles_set_winds is called again.
+ * Time semantics inside a model step [t, t+Δt] (picles_set_wind_grid_mode; LINEAR after every picles_set_wind_grid):
+ *   PICLES_LATTICE_LINEAR  the reference's: the interpolant itself, kinks included.  No lattice knot strictly inside the step:
+ *                          two levels (t, t+Δt), a straight line.  One knot inside: a third level AT the knot, two straight
+ *                          segments (= picles_set_winds_knot).  Two or more knots inside one step: the step is REFUSED with an
+ *                          error text (take Δt <= the lattice's time spacing, or the mode below).
+ *   PICLES_LATTICE_SMOOTH3 for a lattice that tabulates a smooth closure u(x,y,t) (knots at Δt/2 or finer): three levels
+ *                          (t, t+Δt/2, t+Δt), the parabola through them (= picles_set_winds3 with the lattice sampled on the
+ *                          device) — what carries tests/T04_2D_reg_test.jl:166-167's cos(3t/(3600 2π)) forcing to 1e-3 with no
+ *                          host work in the time loop.  An approximation of the closure by design, not of the interpolant. */
 int32_t picles_set_wind_grid(picles_ctx *ctx, int32_t nx, int32_t ny, int32_t nt,
                              double x0, double dx, double y0, double dy, double t0, double dt,
                              const double *u, const double *v, double mesh_x0, double mesh_y0);
+#define PICLES_LATTICE_LINEAR  0
+#define PICLES_LATTICE_SMOOTH3 1
+int32_t picles_set_wind_grid_mode(picles_ctx *ctx, int32_t mode);
+/* The interior knot of the lattice in the window (t, t+dt), as the LINEAR mode classifies it: returns the number of lattice
+ * time knots strictly inside (0, 1, or 2 = "two or more"); *tk = the time of the first one.  A knot closer to either end than
+ * 1e-9 of the lattice spacing counts as that end.  Host arithmetic only; the host layers use it to build the same windows
+ * from host-sampled levels (picles_set_winds_knot).  (The periodic continuation in t has a whole number of
+ * lattice intervals as its period: knots stay at whole multiples of lat_dt from lat_t0.) */
+int32_t picles_lattice_knots(double lat_t0, double lat_dt, double t, double dt, double *tk);
 /* node winds currently on the device (own rows); any pointer may be NULL */
 int32_t picles_get_winds(picles_ctx *ctx, double *u0, double *v0, double *u1, double *v1);
 /* the mid-window level of three-level winds; returns 1 (and writes nothing) when the current winds have two levels */

@@ -135,6 +135,8 @@ typedef struct po_model {
     double *m11, *m22, *pc;    /* per-node projection M = diag(m11, m22) and great-circle coefficient (NULL: Cartesian) */
     double tw0, tw1;
     int wind_static;
+    int wind_knot;             /* three levels, the middle one at the knot twk of a gridded wind (picles_oracle_set_winds_knot): two straight segments */
+    double twk;
     double clock;
     picles_counters cnt;
     char err[256];
@@ -424,6 +426,20 @@ static inline void po_wind(const po_model *M, int64_t idx, double t, double *u, 
         return;
     }
     if (M->order == 0) {
+        if (M->um && M->wind_knot) {
+            /* a gridded wind with one of its time knots inside the step (Utils/WindEmulator.jl:18-43: linear_interpolation in t,
+             * evaluated by the RHS at every stage time, particle_waves_v5.jl:494-495): the lerp of the segment t falls into */
+            if (t < M->twk) {
+                double f = (t - M->tw0) / (M->twk - M->tw0);
+                *u = M->u0[idx] + (M->um[idx] - M->u0[idx]) * f;
+                *v = M->v0[idx] + (M->vm[idx] - M->v0[idx]) * f;
+            } else {
+                double f = (t - M->twk) / (M->tw1 - M->twk);
+                *u = M->um[idx] + (M->u1[idx] - M->um[idx]) * f;
+                *v = M->vm[idx] + (M->v1[idx] - M->vm[idx]) * f;
+            }
+            return;
+        }
         double s = (t - M->tw0) / (M->tw1 - M->tw0);
         if (M->um) {
             double l0 = (2.0 * s - 1.0) * (s - 1.0), lm = 4.0 * s * (1.0 - s), l1 = s * (2.0 * s - 1.0);
@@ -434,16 +450,64 @@ static inline void po_wind(const po_model *M, int64_t idx, double t, double *u, 
             *v = M->v0[idx] + (M->v1[idx] - M->v0[idx]) * s;
         }
     } else {
-        double s = (t - M->tw0) * (1.0 / (M->tw1 - M->tw0));
-        double s1 = s - 1.0;
-        double bu = 0.0, bv = 0.0;
-        if (M->um) {
-            bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
-            bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
+        /* kernel order (physics.h, wind_shape / wind_eval; kernels.h, load_wind): u0 + s du + g(s) bu with g = s (s - 1) and the
+         * Newton coefficients of the parabola, or g = max(s - sk, 0) with the first segment's slope du = (uk - u0)/sk and the jump
+         * of the slope bu = (u1 - uk)/(1 - sk) - du */
+        const double idt = 1.0 / (M->tw1 - M->tw0);
+        double s = (t - M->tw0) * idt;
+        double du = M->u1[idx] - M->u0[idx], dv = M->v1[idx] - M->v0[idx], bu = 0.0, bv = 0.0, g;
+        if (M->um && M->wind_knot) {
+            const double sk = (M->twk - M->tw0) * idt, isk = 1.0 / sk, i1sk = 1.0 / (1.0 - sk);
+            du = (M->um[idx] - M->u0[idx]) * isk; dv = (M->vm[idx] - M->v0[idx]) * isk;
+            bu = (M->u1[idx] - M->um[idx]) * i1sk - du; bv = (M->v1[idx] - M->vm[idx]) * i1sk - dv;
+            double sp = s - sk;
+            g = (sp > 0.0) ? sp : 0.0;
+        } else {
+            if (M->um) {
+                bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
+                bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
+            }
+            g = s * (s - 1.0);
         }
-        *u = PO_FMA(PO_FMA(bu, s1, M->u1[idx] - M->u0[idx]), s, M->u0[idx]);
-        *v = PO_FMA(PO_FMA(bv, s1, M->v1[idx] - M->v0[idx]), s, M->v0[idx]);
+        *u = PO_FMA(bu, g, PO_FMA(du, s, M->u0[idx]));
+        *v = PO_FMA(bv, g, PO_FMA(dv, s, M->v0[idx]));
     }
+}
+
+/* d/dt of the same interpolant at t (the explicit time derivative the Rosenbrock23 attempt needs) */
+static inline void po_wind_dt(const po_model *M, int64_t idx, double t, double *dudt, double *dvdt)
+{
+    *dudt = *dvdt = 0.0;
+    if (M->wind_static) return;
+    const double idt = 1.0 / (M->tw1 - M->tw0);
+    if (M->um && M->wind_knot) {
+        if (M->order == 0) {
+            if (t < M->twk) {
+                *dudt = (M->um[idx] - M->u0[idx]) / (M->twk - M->tw0);
+                *dvdt = (M->vm[idx] - M->v0[idx]) / (M->twk - M->tw0);
+            } else {
+                *dudt = (M->u1[idx] - M->um[idx]) / (M->tw1 - M->twk);
+                *dvdt = (M->v1[idx] - M->vm[idx]) / (M->tw1 - M->twk);
+            }
+            return;
+        }
+        const double s = (t - M->tw0) * idt;
+        const double sk = (M->twk - M->tw0) * idt, isk = 1.0 / sk, i1sk = 1.0 / (1.0 - sk);
+        const double du = (M->um[idx] - M->u0[idx]) * isk, dv = (M->vm[idx] - M->v0[idx]) * isk;
+        const double bu = (M->u1[idx] - M->um[idx]) * i1sk - du, bv = (M->v1[idx] - M->vm[idx]) * i1sk - dv;
+        *dudt = ((s >= sk) ? du + bu : du) * idt;
+        *dvdt = ((s >= sk) ? dv + bv : dv) * idt;
+        return;
+    }
+    /* parabola (two levels: bu = 0): (du + (2 s - 1) bu) / (tw1 - tw0) */
+    double s21 = PO_FMA(2.0, (t - M->tw0) * idt, -1.0);
+    double bu = 0.0, bv = 0.0;
+    if (M->um) {
+        bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
+        bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
+    }
+    *dudt = PO_FMA(bu, s21, M->u1[idx] - M->u0[idx]) * idt;
+    *dvdt = PO_FMA(bv, s21, M->v1[idx] - M->v0[idx]) * idt;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -906,17 +970,7 @@ static double po_ros23_try(const po_model *M, int64_t idx, const double u0[5], c
     double uw, vw, uw1, vw1;
     po_wind(M, idx, t, &uw, &vw);
     double dudt = 0.0, dvdt = 0.0;
-    if (!M->wind_static) {      /* d/dt of the window's interpolant at t: (du + (2 s - 1) bu) / (tw1 - tw0) */
-        double idt = 1.0 / (M->tw1 - M->tw0);
-        double s21 = PO_FMA(2.0, (t - M->tw0) * idt, -1.0);
-        double bu = 0.0, bv = 0.0;
-        if (M->um) {
-            bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
-            bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
-        }
-        dudt = PO_FMA(bu, s21, M->u1[idx] - M->u0[idx]) * idt;
-        dvdt = PO_FMA(bv, s21, M->v1[idx] - M->v0[idx]) * idt;
-    }
+    po_wind_dt(M, idx, t, &dudt, &dvdt);
     const double seeds[4][5] = {{1, 0, 0, 0, 0}, {0, 1, 0, 0, 0}, {0, 0, 1, 0, 0}, {0, 0, 0, dudt, dvdt}};
     double fj[3], dfs[4][3] = {{0}};
     const int ns = M->wind_static ? 3 : 4;        /* static winds: dT = 0, its terms are not formed at all */
@@ -1391,6 +1445,7 @@ PO_EXPORT int32_t picles_oracle_set_winds3(po_model *M, const double *u0, const 
     memcpy(M->u0, u0, M->N * 8);
     memcpy(M->v0, v0, M->N * 8);
     M->tw0 = t0;
+    M->wind_knot = 0;
     free(M->um); free(M->vm);
     M->um = M->vm = NULL;
     if (u1 && v1 && t1 != t0) {
@@ -1406,6 +1461,18 @@ PO_EXPORT int32_t picles_oracle_set_winds3(po_model *M, const double *u0, const 
         M->wind_static = 1;
         M->tw1 = t0;
     }
+    return 0;
+}
+/* three levels, the middle one at a knot tk of a gridded wind, t0 < tk < t1 (the product's picles_set_winds_knot) */
+PO_EXPORT int32_t picles_oracle_set_winds_knot(po_model *M, const double *u0, const double *v0, double t0,
+                                               const double *uk, const double *vk, double tk,
+                                               const double *u1, const double *v1, double t1)
+{
+    if (!uk || !vk || !u1 || !v1 || !(t0 < tk && tk < t1)) return -2;
+    int32_t rc = picles_oracle_set_winds3(M, u0, v0, t0, uk, vk, u1, v1, t1);
+    if (rc) return rc;
+    M->wind_knot = 1;
+    M->twk = tk;
     return 0;
 }
 PO_EXPORT int32_t picles_oracle_set_winds(po_model *M, const double *u0, const double *v0, double t0,

@@ -86,10 +86,11 @@ class PiclesTiming(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+LATTICE_LINEAR, LATTICE_SMOOTH3 = 0, 1
 STEP_ZERO_FIRST = 1
 STEP_MOVIE = 2
 STEP_ATOMIC = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 SLAB_ID_BYTES = 128
 
 ROWS_ALL, ROWS_EDGE, ROWS_INTERIOR = 0, 1, 2
@@ -107,10 +108,14 @@ SYMBOLS = {
     "picles_abi_version": (C.c_int32, []),
     "picles_set_winds": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, C.c_double]),
     "picles_set_winds3": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double]),
+    "picles_set_winds_knot": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, C.c_double,
+                                          c_double_p, c_double_p, C.c_double]),
     "picles_get_winds_mid": (C.c_int32, [_VP, c_double_p, c_double_p]),
     "picles_set_metric": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p]),
     "picles_set_wind_grid": (C.c_int32, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                          C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, C.c_double, C.c_double]),
+    "picles_set_wind_grid_mode": (C.c_int32, [_VP, C.c_int32]),
+    "picles_lattice_knots": (C.c_int32, [C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]),
     "picles_get_winds": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p, c_double_p]),
     "picles_seed": (C.c_int32, [_VP, C.c_double]),
     "picles_time_step": (C.c_int32, [_VP, C.c_double, C.c_int32]),

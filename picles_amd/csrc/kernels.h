@@ -113,9 +113,17 @@ __device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, lon
         const double u1 = A.u1[t], v1 = A.v1[t];
         w.du = u1 - w.u0;
         w.dv = v1 - w.v0;
-        if (A.um) {      /* three levels: curvature term of the parabola through them (physics.h, Wind) */
-            w.bu = 2.0 * ((w.u0 + u1) - 2.0 * A.um[t]);
-            w.bv = 2.0 * ((w.v0 + v1) - 2.0 * A.vm[t]);
+        if (A.um) {
+            const double um = A.um[t], vm = A.vm[t];
+            if (P.wind_sk > 0.0) {   /* three levels, the middle one at a knot of the wind lattice: two straight segments (physics.h, Wind) */
+                w.du = (um - w.u0) * P.wind_isk;
+                w.dv = (vm - w.v0) * P.wind_isk;
+                w.bu = (u1 - um) * P.wind_i1sk - w.du;
+                w.bv = (v1 - vm) * P.wind_i1sk - w.dv;
+            } else {                 /* three levels: curvature term of the parabola through them */
+                w.bu = 2.0 * ((w.u0 + u1) - 2.0 * um);
+                w.bv = 2.0 * ((w.v0 + v1) - 2.0 * vm);
+            }
         }
     }
     return w;

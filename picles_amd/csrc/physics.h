@@ -51,6 +51,10 @@ struct KParams {
     /* winds */
     int wind_static;
     double tw0, inv_dtw;
+    /* three-level windows come in two forms (physics.h, Wind): wind_sk == 0: the parabola through (t0, mid, t1) — node samples of a
+     * smooth closure; 0 < wind_sk < 1: the piecewise-linear function with ONE knot at s = wind_sk — the exact form of a gridded wind
+     * (Utils/WindEmulator.jl:18-43, linear_interpolation in t) one of whose time knots falls inside the model step */
+    double wind_sk, wind_isk, wind_i1sk;   /* s of the knot, 1/sk, 1/(1 - sk) */
 };
 
 /* Dormand–Prince 5(4) */
@@ -212,16 +216,37 @@ struct Vec5 {
     double lne, cx, cy, x, y;
 };
 
-/* node wind over the step window [tw0, tw1], s = (t - tw0)/(tw1 - tw0):  u(s) = u0 + s (du + (s - 1) bu)  — the parabola through
+/* node wind over the step window [tw0, tw1], s = (t - tw0)/(tw1 - tw0):  u(s) = u0 + s du + s (s - 1) bu  — the parabola through
  * the three levels u0 = u(tw0), um = u((tw0+tw1)/2), u1 = u(tw1) in Newton form, du = u1 - u0, bu = 2 ((u0 + u1) - 2 um).
- * Two-level winds (picles_set_winds, the device-sampled lattice) have bu = bv = 0 and are the straight line, bit for bit what
- * the two-level code computed: fma(0, s - 1, du) = du.  The reference calls the closures u(x,y,t), v(x,y,t) at every stage time
+ * Two-level winds (picles_set_winds, a lattice window without a knot) have bu = bv = 0 and are the straight line, bit for bit what
+ * the two-level code computed: fma(0, g, fma(du, s, u0)) = fma(du, s, u0).  The reference calls the closures u(x,y,t), v(x,y,t) at every stage time
  * (particle_waves_v5.jl:494-495); for a forcing of angular frequency ω the line misses it by (ω Δt)²/8 of its amplitude at
  * mid-step, the parabola by (ω Δt)³/125 (T04_2D_reg_test.jl:167 with Δt = 20 min: 3.2e-3 against 3.2e-5). */
+/* The other three-level form (P.wind_sk in (0,1)): a gridded wind is piecewise linear in t with kinks at the lattice's time knots, and
+ * the RHS sees the kink when a knot falls inside the step (the reference evaluates linear_interpolation((x,y,t), u) at every stage
+ * time).  With the knot at s = sk and the node's level there, uk:  u(s) = u0 + s du + max(s - sk, 0) bu,  du = (uk - u0)/sk the
+ * first segment's slope and bu = (u1 - uk)/(1 - sk) - du the change of slope at the knot.  Same six numbers per node, one kernel-
+ * uniform (scalar) branch per evaluation; like the parabola it returns level 0 itself at s = 0 (the fused step's remesh reads that
+ * level from its plane, the stand-alone remesh evaluates the window at its start: the two must agree to the bit). */
 struct Wind {
-    double u0, v0, du, dv; /* level 0 and (level1 - level0) */
-    double bu, bv;         /* curvature term of the three-level window (0: linear in t) */
+    double u0, v0, du, dv; /* level 0 and (level1 - level0) [knot form: the first segment's slope per unit s] */
+    double bu, bv;         /* curvature term of the three-level window (0: linear in t) [knot form: the slope's jump at the knot] */
 };
+/* both forms are  u(s) = u0 + s du + g(s) bu  with one shape function per window form, evaluated once per stage time for u and v:
+ * g = s (s - 1) (parabola; two levels: bu = 0, the straight line) or g = max(s - sk, 0) (knot) */
+PM_HD double wind_shape(const KParams &P, double s)
+{
+    double sp = s - P.wind_sk;
+    sp = (sp > 0.0) ? sp : 0.0;
+    return (P.wind_sk > 0.0) ? sp : s * (s - 1.0);
+}
+PM_HD double wind_eval(double u0, double du, double bu, double s, double g) { return PM_FMA(bu, g, PM_FMA(du, s, u0)); }
+/* d/ds of the same */
+PM_HD double wind_slope(const KParams &P, double du, double bu, double s)
+{
+    if (P.wind_sk > 0.0) return (s >= P.wind_sk) ? du + bu : du;
+    return PM_FMA(bu, PM_FMA(2.0, s, -1.0), du);
+}
 
 struct PStats {
     unsigned int rhs, acc, rej;
@@ -268,9 +293,9 @@ PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double 
         v = w.v0;
     } else {
         double s = (t - P.tw0) * P.inv_dtw;
-        double s1 = s - 1.0;
-        u = PM_FMA(PM_FMA(w.bu, s1, w.du), s, w.u0);
-        v = PM_FMA(PM_FMA(w.bv, s1, w.dv), s, w.v0);
+        double g = wind_shape(P, s);
+        u = wind_eval(w.u0, w.du, w.bu, s, g);
+        v = wind_eval(w.v0, w.dv, w.bv, s, g);
     }
 }
 template <bool STATIC>
@@ -278,8 +303,8 @@ PM_HD void wind_stage(const KParams &P, const Wind &w, double t, WindD &d)
 {
     if (!STATIC) {
         double s = (t - P.tw0) * P.inv_dtw;
-        double s1 = s - 1.0;
-        wind_derive_stage(P, PM_FMA(PM_FMA(w.bu, s1, w.du), s, w.u0), PM_FMA(PM_FMA(w.bv, s1, w.dv), s, w.v0), d);
+        double g = wind_shape(P, s);
+        wind_derive_stage(P, wind_eval(w.u0, w.du, w.bu, s, g), wind_eval(w.v0, w.dv, w.bv, s, g), d);
     }
 }
 
@@ -600,9 +625,9 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     seeds[0] = {1.0, 0.0, 0.0, 0.0, 0.0};
     seeds[1] = {0.0, 1.0, 0.0, 0.0, 0.0};
     seeds[2] = {0.0, 0.0, 1.0, 0.0, 0.0};
-    if (!STATIC) {      /* du/dt, dv/dt of the window's parabola at t: (du + (2 s - 1) bu) / (tw1 - tw0) */
-        const double s21 = PM_FMA(2.0, (t - P.tw0) * P.inv_dtw, -1.0);
-        seeds[NS - 1] = {0.0, 0.0, 0.0, PM_FMA(w.bu, s21, w.du) * P.inv_dtw, PM_FMA(w.bv, s21, w.dv) * P.inv_dtw};
+    if (!STATIC) {      /* du/dt, dv/dt of the window's interpolant at t: parabola (du + (2 s - 1) bu) / (tw1 - tw0); knot form: the segment's slope */
+        const double s_ = (t - P.tw0) * P.inv_dtw;
+        seeds[NS - 1] = {0.0, 0.0, 0.0, wind_slope(P, w.du, w.bu, s_) * P.inv_dtw, wind_slope(P, w.dv, w.bv, s_) * P.inv_dtw};
     }
     const bool tv = !STATIC && !P.wind_static;   /* a time-varying instantiation may run with static winds: no dT terms then */
     wind_stage<STATIC>(P, w, t, W);

@@ -351,34 +351,42 @@ __device__ __forceinline__ void lattice_coord(double c, int n, int &i0, double &
     f = w - (double)i0;
 }
 
-__global__ void __launch_bounds__(256) k_wind_sample(GridP G, WindGrid Wg, double t, double *uo, double *vo, long long n)
+/* NT time levels per launch (the spatial cell and its weights are shared): level q at time tq[q] goes to (uo[q], vo[q]) */
+struct WindSampleOut { double t[2]; double *u[2], *v[2]; };
+template <int NT>
+__global__ void __launch_bounds__(256) k_wind_sample(GridP G, WindGrid Wg, WindSampleOut O, long long n)
 {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int i = (int)(k % G.Nx), j = (int)(k / G.Nx) + G.j_begin;
     double x = Wg.mesh_x0 + (double)i * Wg.mesh_dx, y = Wg.mesh_y0 + (double)j * Wg.mesh_dy;
-    int ix, iy, it;
-    double fx, fy, ft;
+    int ix, iy;
+    double fx, fy;
     lattice_coord((x - Wg.x0) * Wg.inv_dx, Wg.nx, ix, fx);
     lattice_coord((y - Wg.y0) * Wg.inv_dy, Wg.ny, iy, fy);
-    lattice_coord((t - Wg.t0) * Wg.inv_dt, Wg.nt, it, ft);
     size_t sx = 1, sy = (size_t)Wg.nx, st = (size_t)Wg.nx * Wg.ny;
-    size_t b = ix * sx + iy * sy + it * st;
     const double *F[2] = {Wg.u, Wg.v};
-    double out[2];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const double *f = F[c];
-        double c00 = f[b] + (f[b + sx] - f[b]) * fx;
-        double c10 = f[b + sy] + (f[b + sy + sx] - f[b + sy]) * fx;
-        double c01 = f[b + st] + (f[b + st + sx] - f[b + st]) * fx;
-        double c11 = f[b + st + sy] + (f[b + st + sy + sx] - f[b + st + sy]) * fx;
-        double c0 = c00 + (c10 - c00) * fy;
-        double c1 = c01 + (c11 - c01) * fy;
-        out[c] = c0 + (c1 - c0) * ft;
+    for (int q = 0; q < NT; q++) {
+        int it;
+        double ft;
+        lattice_coord((O.t[q] - Wg.t0) * Wg.inv_dt, Wg.nt, it, ft);
+        size_t b = ix * sx + iy * sy + it * st;
+        double out[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const double *f = F[c];
+            double c00 = f[b] + (f[b + sx] - f[b]) * fx;
+            double c10 = f[b + sy] + (f[b + sy + sx] - f[b + sy]) * fx;
+            double c01 = f[b + st] + (f[b + st + sx] - f[b + st]) * fx;
+            double c11 = f[b + st + sy] + (f[b + st + sy + sx] - f[b + st + sy]) * fx;
+            double c0 = c00 + (c10 - c00) * fy;
+            double c1 = c01 + (c11 - c01) * fy;
+            out[c] = c0 + (c1 - c0) * ft;
+        }
+        O.u[q][k] = out[0];
+        O.v[q][k] = out[1];
     }
-    uo[k] = out[0];
-    vo[k] = out[1];
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -445,6 +453,8 @@ struct picles_ctx {
     double *d_wgu = nullptr, *d_wgv = nullptr;
     double wind_t1 = 0.0;          /* time level currently held in (u1, v1) */
     bool wind_t1_valid = false;
+    int wind_grid_mode = PICLES_LATTICE_LINEAR;
+    double wg_t0 = 0.0, wg_dt = 0.0;   /* the lattice's first time knot and spacing as the caller gave them (knot times are computed from these) */
     bool ord_valid = false;        /* the previous fused step filed a dispatch order (kernels.h: Arrays::ord) with ... */
     int ord_nblk = 0;              /* ... this many workgroups: the whole grid, or the interior rows of a slab */
     double *um_buf = nullptr, *vm_buf = nullptr;   /* mid-window wind level (picles_set_winds3); A.um / A.vm point here while in use */
@@ -616,7 +626,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.init_type = m->init_type;
     P.def_lne = m->default_particle[0]; P.def_cx = m->default_particle[1]; P.def_cy = m->default_particle[2];
     P.min_e = m->minimal_state[0]; P.min_m2 = m->minimal_state[1];
-    P.wind_static = 1; P.tw0 = 0.0; P.inv_dtw = 0.0;
+    P.wind_static = 1; P.tw0 = 0.0; P.inv_dtw = 0.0; P.wind_sk = P.wind_isk = P.wind_i1sk = 0.0;
 
     GridP &G = c->G;
     G.Nx = g->Nx; G.Ny = g->Ny; G.periodic_x = (g->periodic_x != 0); G.periodic_y = (g->periodic_y == 1);
@@ -761,9 +771,24 @@ PX_EXPORT int32_t picles_sync(picles_ctx *c)
 
 PX_EXPORT double picles_clock(const picles_ctx *c) { return c ? c->clock : 0.0; }
 
-PX_EXPORT int32_t picles_set_winds3(picles_ctx *c, const double *u0, const double *v0, double t0,
-                                    const double *um, const double *vm,
-                                    const double *u1, const double *v1, double t1)
+/* form of a three-level window: the parabola through (t0, (t0+t1)/2, t1), or two straight segments meeting at the knot tk */
+static void wind_window_form(picles_ctx *c, double t0, double t1, bool knot, double tk)
+{
+    KParams &P = c->P;
+    P.tw0 = t0;
+    P.inv_dtw = 1.0 / (t1 - t0);
+    if (knot) {
+        P.wind_sk = (tk - t0) * P.inv_dtw;
+        P.wind_isk = 1.0 / P.wind_sk;
+        P.wind_i1sk = 1.0 / (1.0 - P.wind_sk);
+    } else {
+        P.wind_sk = P.wind_isk = P.wind_i1sk = 0.0;
+    }
+}
+
+static int set_wind_levels(picles_ctx *c, const double *u0, const double *v0, double t0,
+                           const double *um, const double *vm, bool knot, double tk,
+                           const double *u1, const double *v1, double t1)
 {
     if (!c || !u0 || !v0) return -1;
     HIPCHK(c, hipSetDevice(c->device));
@@ -775,18 +800,19 @@ PX_EXPORT int32_t picles_set_winds3(picles_ctx *c, const double *u0, const doubl
     HIPCHK(c, hipMemcpyAsync(A.u0, u0, b, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(A.v0, v0, b, hipMemcpyHostToDevice, c->stream));
     const bool two = u1 && v1 && t1 != t0;
+    const bool three = two && um && vm;
     if (two) {
         HIPCHK(c, hipMemcpyAsync(A.u1, u1, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(A.v1, v1, b, hipMemcpyHostToDevice, c->stream));
         c->P.wind_static = 0;
-        c->P.tw0 = t0;
-        c->P.inv_dtw = 1.0 / (t1 - t0);
+        wind_window_form(c, t0, t1, three && knot, tk);
     } else {
         c->P.wind_static = 1;
         c->P.tw0 = t0;
         c->P.inv_dtw = 0.0;
+        c->P.wind_sk = c->P.wind_isk = c->P.wind_i1sk = 0.0;
     }
-    if (two && um && vm) {               /* third level: the planes exist from the first three-level call on */
+    if (three) {                         /* third level: the planes exist from the first three-level call on */
         if (!c->um_buf) {
             HIPCHK(c, hipMalloc(&c->um_buf, b));
             HIPCHK(c, hipMalloc(&c->vm_buf, b));
@@ -801,10 +827,27 @@ PX_EXPORT int32_t picles_set_winds3(picles_ctx *c, const double *u0, const doubl
     return 0;
 }
 
+PX_EXPORT int32_t picles_set_winds3(picles_ctx *c, const double *u0, const double *v0, double t0,
+                                    const double *um, const double *vm,
+                                    const double *u1, const double *v1, double t1)
+{
+    return set_wind_levels(c, u0, v0, t0, um, vm, false, 0.0, u1, v1, t1);
+}
+
 PX_EXPORT int32_t picles_set_winds(picles_ctx *c, const double *u0, const double *v0, double t0,
                                    const double *u1, const double *v1, double t1)
 {
-    return picles_set_winds3(c, u0, v0, t0, nullptr, nullptr, u1, v1, t1);
+    return set_wind_levels(c, u0, v0, t0, nullptr, nullptr, false, 0.0, u1, v1, t1);
+}
+
+PX_EXPORT int32_t picles_set_winds_knot(picles_ctx *c, const double *u0, const double *v0, double t0,
+                                        const double *uk, const double *vk, double tk,
+                                        const double *u1, const double *v1, double t1)
+{
+    if (!c) return -1;
+    if (!uk || !vk || !u1 || !v1) return fail(c, -2, "picles_set_winds_knot needs all three levels");
+    if (!(t0 < tk && tk < t1)) return fail(c, -2, "picles_set_winds_knot: the knot must lie strictly inside the window, t0 < tk < t1");
+    return set_wind_levels(c, u0, v0, t0, uk, vk, true, tk, u1, v1, t1);
 }
 
 static inline unsigned nblocks(long long n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -847,32 +890,106 @@ PX_EXPORT int32_t picles_set_wind_grid(picles_ctx *c, int32_t nx, int32_t ny, in
     w.x0 = x0; w.inv_dx = 1.0 / dx; w.y0 = y0; w.inv_dy = 1.0 / dy; w.t0 = t0; w.inv_dt = 1.0 / dt;
     w.mesh_x0 = mesh_x0; w.mesh_y0 = mesh_y0; w.mesh_dx = c->g.dx; w.mesh_dy = c->g.dy;
     w.u = c->d_wgu; w.v = c->d_wgv;
-    c->A.um = c->A.vm = nullptr;         /* the lattice is linear in t between its knots: two levels per window */
+    c->wg_t0 = t0; c->wg_dt = dt;
+    c->A.um = c->A.vm = nullptr;
+    c->P.wind_sk = c->P.wind_isk = c->P.wind_i1sk = 0.0;
     c->wind_grid_on = true;
+    c->wind_grid_mode = PICLES_LATTICE_LINEAR;
     c->wind_t1_valid = false;
     return 0;
 }
 
-/* sample the lattice for the step [t, t+dt] into (u0,v0) / (u1,v1); reuses the level the previous
- * step left in (u1,v1) by swapping the plane pointers */
-static int wind_grid_prepare(picles_ctx *c, double t, double dt, hipStream_t s)
+PX_EXPORT int32_t picles_set_wind_grid_mode(picles_ctx *c, int32_t mode)
+{
+    if (!c) return -1;
+    if (mode != PICLES_LATTICE_LINEAR && mode != PICLES_LATTICE_SMOOTH3) return fail(c, -2, "unknown wind lattice mode");
+    if (!c->wind_grid_on) return fail(c, -2, "picles_set_wind_grid first");
+    { int rc = flush(c); if (rc) return rc; }
+    c->wind_grid_mode = mode;
+    c->wind_t1_valid = false;
+    return 0;
+}
+
+/* time knots of the lattice strictly inside (t, t + dt): 0, 1 or 2 (= two or more); *tk = the first one.  Knots sit at whole
+ * multiples of lat_dt from lat_t0 (the periodic continuation's period is a whole number of intervals); one closer to an end of the
+ * window than 1e-9 intervals is that end (600-second steps against 900-second knots must not see a "knot" 1e-13 s before t + dt). */
+PX_EXPORT int32_t picles_lattice_knots(double lat_t0, double lat_dt, double t, double dt, double *tk)
+{
+    const double eps = 1e-9;
+    const double c0 = (t - lat_t0) / lat_dt, c1 = (t + dt - lat_t0) / lat_dt;
+    const double k0 = __builtin_floor(c0 + eps) + 1.0;
+    if (!(k0 < c1 - eps)) return 0;
+    if (tk) *tk = lat_t0 + k0 * lat_dt;
+    return (k0 + 1.0 < c1 - eps) ? 2 : 1;
+}
+
+/* what the step window [t, t + dt] over the lattice looks like: levels, form, time of the middle level */
+struct WindowPlan { bool three; bool knot; double tm; };
+static int wind_window_plan(picles_ctx *c, double t, double dt, WindowPlan &W)
+{
+    W = {false, false, 0.0};
+    if (c->wind_grid_mode == PICLES_LATTICE_SMOOTH3) {
+        W.three = true;
+        W.tm = t + 0.5 * dt;
+        return 0;
+    }
+    double tk = 0.0;
+    const int nk = picles_lattice_knots(c->wg_t0, c->wg_dt, t, dt, &tk);
+    if (nk >= 2) {
+        char buf[320];
+        snprintf(buf, sizeof buf, "the model step [%.17g, %.17g] contains two or more time knots of the wind lattice (spacing %.17g s): "
+                 "its piecewise-linear wind cannot be carried by one window — take model steps no longer than the lattice spacing, "
+                 "or picles_set_wind_grid_mode(PICLES_LATTICE_SMOOTH3) if the lattice tabulates a smooth closure", t, t + dt, c->wg_dt);
+        return fail(c, -7, buf);
+    }
+    if (nk == 1) { W.three = true; W.knot = true; W.tm = tk; }
+    return 0;
+}
+
+/* sample the levels of the window [t, t + dt] that are not on the device yet: level 1 at t + dt into (u1, v1), the middle level
+ * (the knot, or t + dt/2) into (um, vm) when the window has one, level 0 into (u0, v0) when `with0`; sets the window's form */
+static int wind_window_sample(picles_ctx *c, const WindowPlan &W, double t, double dt, bool with0, hipStream_t s)
 {
     Arrays &A = c->A;
     dim3 grid(nblocks(A.n, 256)), block(256);
-    if (c->wind_t1_valid && c->wind_t1 == t) {
-        std::swap(A.u0, A.u1);
-        std::swap(A.v0, A.v1);
-    } else {
-        hipLaunchKernelGGL(k_wind_sample, grid, block, 0, s, c->G, c->wg, t, A.u0, A.v0, A.n);
+    if (W.three && !c->um_buf) {
+        HIPCHK(c, hipMalloc(&c->um_buf, (size_t)A.n * 8));
+        HIPCHK(c, hipMalloc(&c->vm_buf, (size_t)A.n * 8));
     }
-    hipLaunchKernelGGL(k_wind_sample, grid, block, 0, s, c->G, c->wg, t + dt, A.u1, A.v1, A.n);
+    if (with0) {
+        WindSampleOut O = {{t, 0.0}, {A.u0, nullptr}, {A.v0, nullptr}};
+        hipLaunchKernelGGL(k_wind_sample<1>, grid, block, 0, s, c->G, c->wg, O, A.n);
+    }
+    if (W.three) {
+        WindSampleOut O = {{W.tm, t + dt}, {c->um_buf, A.u1}, {c->vm_buf, A.v1}};
+        hipLaunchKernelGGL(k_wind_sample<2>, grid, block, 0, s, c->G, c->wg, O, A.n);
+        A.um = c->um_buf; A.vm = c->vm_buf;
+    } else {
+        WindSampleOut O = {{t + dt, 0.0}, {A.u1, nullptr}, {A.v1, nullptr}};
+        hipLaunchKernelGGL(k_wind_sample<1>, grid, block, 0, s, c->G, c->wg, O, A.n);
+        A.um = A.vm = nullptr;
+    }
     HIPCHK(c, hipGetLastError());
     c->wind_t1 = t + dt;
     c->wind_t1_valid = true;
     c->P.wind_static = 0;
-    c->P.tw0 = t;
-    c->P.inv_dtw = 1.0 / dt;
+    wind_window_form(c, t, t + dt, W.knot, W.tm);
     return 0;
+}
+
+/* sample the lattice for the step [t, t+dt] into (u0,v0) / (u1,v1) (+ the middle level); reuses the level the previous
+ * step left in (u1,v1) by swapping the plane pointers */
+static int wind_grid_prepare(picles_ctx *c, double t, double dt, hipStream_t s)
+{
+    Arrays &A = c->A;
+    WindowPlan W;
+    { int rc = wind_window_plan(c, t, dt, W); if (rc) return rc; }
+    const bool reuse = c->wind_t1_valid && c->wind_t1 == t;
+    if (reuse) {
+        std::swap(A.u0, A.u1);
+        std::swap(A.v0, A.v1);
+    }
+    return wind_window_sample(c, W, t, dt, !reuse, s);
 }
 
 PX_EXPORT int32_t picles_get_winds(picles_ctx *c, double *u0, double *v0, double *u1, double *v1)
@@ -907,8 +1024,11 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
     if (c->ext_streams) HIPCHK(c, hipDeviceSynchronize());   /* earlier steps may still run on caller / ring streams */
     c->clock = t0;
     if (c->wind_grid_on) {   /* winds at t = 0.0 seed the particles (run.jl:213-215) */
+        /* only level 0 is read (k_seed evaluates the window at its start); the window's end is sampled at the seed time scale, whatever
+         * lies between: a plain two-level window, replaced by the first step's own */
         c->wind_t1_valid = false;
-        int rc = wind_grid_prepare(c, 0.0, c->od.timestep, c->stream);
+        const WindowPlan two = {false, false, 0.0};
+        int rc = wind_window_sample(c, two, 0.0, c->od.timestep, true, c->stream);
         if (rc) return rc;
     }
     c->pending = false;
@@ -954,19 +1074,19 @@ PX_EXPORT int32_t picles_begin_step(picles_ctx *c, double dt, int32_t flags)
     if (!c) return -1;
     if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
     { int rc = flush(c); if (rc) return rc; }
-    c->step_dt = dt;
-    c->step_flags = flags;
-    c->edge_pending = false;
-    c->cur ^= 1;            /* this step's records go to (and are scattered from) rec_buf[cur] */
-    c->mr_w = (c->mr_w + 1) % 5;
-    c->step_fresh = true;   /* the first advance_rows of the step clears max_reach on ITS stream */
-    if (c->wind_grid_on) {
+    if (c->wind_grid_on) {  /* (first: a window the lattice cannot carry is refused before the step has changed anything) */
         HIPCHK(c, hipSetDevice(c->device));
         if (c->ext_streams && !c->ring_orders) HIPCHK(c, hipDeviceSynchronize());   /* previous step (any stream) done with the wind planes */
         int rc = wind_grid_prepare(c, c->clock, dt, c->stream);
         if (rc) return rc;
         /* caller-stream launches wait for the sampler through ev_ctx (step_prologue) */
     }
+    c->step_dt = dt;
+    c->step_flags = flags;
+    c->edge_pending = false;
+    c->cur ^= 1;            /* this step's records go to (and are scattered from) rec_buf[cur] */
+    c->mr_w = (c->mr_w + 1) % 5;
+    c->step_fresh = true;   /* the first advance_rows of the step clears max_reach on ITS stream */
     return 0;
 }
 
@@ -1103,6 +1223,8 @@ PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
         /* earlier launches on other streams read the planes (the native slab ring orders its own streams with events) */
         if (c->ext_streams && !c->ring_orders) HIPCHK(c, hipDeviceSynchronize());
         if (c->pending) {
+            WindowPlan W;
+            { int rc = wind_window_plan(c, c->clock, dt, W); if (rc) return rc; }
             if (!A.uP) {
                 HIPCHK(c, hipMalloc(&A.uP, (size_t)A.n * 8));
                 HIPCHK(c, hipMalloc(&A.vP, (size_t)A.n * 8));
@@ -1111,12 +1233,8 @@ PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
             A.uP = A.u0; A.vP = A.v0;
             A.u0 = A.u1; A.v0 = A.v1;
             A.u1 = tu; A.v1 = tv;
-            dim3 grid(nblocks(A.n, 256)), block(256);
-            hipLaunchKernelGGL(k_wind_sample, grid, block, 0, c->stream, c->G, c->wg, c->clock + dt, A.u1, A.v1, A.n);
-            HIPCHK(c, hipGetLastError());
-            c->wind_t1 = c->clock + dt;
-            c->P.tw0 = c->clock;
-            c->P.inv_dtw = 1.0 / dt;
+            int rc = wind_window_sample(c, W, c->clock, dt, false, c->stream);
+            if (rc) return rc;
         } else {
             int rc = wind_grid_prepare(c, c->clock, dt, c->stream);
             if (rc) return rc;

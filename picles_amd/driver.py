@@ -85,13 +85,18 @@ class HipModel:
         _check(self.lib, self.h, rc, what)
 
     # ---- inputs ----
-    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0, um=None, vm=None):
-        """node winds of the window [t0, t1]: one level (static), two (linear in t) or three (um, vm at (t0+t1)/2: parabola)"""
+    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0, um=None, vm=None, tk=None):
+        """node winds of the window [t0, t1]: one level (static), two (linear in t) or three — (um, vm) at (t0+t1)/2: the parabola;
+        with `tk`: (um, vm) at the knot tk of a gridded wind, two straight segments (picles_set_winds_knot)"""
         u0, v0 = _col(u0, self.N), _col(v0, self.N)
         if u1 is not None:
             u1, v1 = _col(u1, self.N), _col(v1, self.N)
         if um is not None:
             um, vm = _col(um, self.N), _col(vm, self.N)
+            if tk is not None:
+                self._ck(self.lib.picles_set_winds_knot(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(um), K.dptr(vm), float(tk),
+                                                        K.dptr(u1), K.dptr(v1), t1), "picles_set_winds_knot")
+                return
             self._ck(self.lib.picles_set_winds3(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(um), K.dptr(vm), K.dptr(u1), K.dptr(v1), t1),
                      "picles_set_winds3")
             return
@@ -103,12 +108,17 @@ class HipModel:
         a = [_col(x, self.N) for x in (m11, m22, pc)]
         self._ck(self.lib.picles_set_metric(self.h, K.dptr(a[0]), K.dptr(a[1]), K.dptr(a[2])), "picles_set_metric")
 
-    def set_wind_grid(self, lat: dict, mesh_x0: float, mesh_y0: float):
-        """upload an (x,y,t) wind lattice; the device samples it every step (picles_set_wind_grid)"""
+    def set_wind_grid(self, lat: dict, mesh_x0: float, mesh_y0: float, time_mode: str = "linear"):
+        """upload an (x,y,t) wind lattice; the device samples it every step (picles_set_wind_grid).  time_mode "linear": the
+        interpolant itself, time knots inside a step included (PICLES_LATTICE_LINEAR); "smooth3": the parabola through the lattice
+        sampled at t, t+Δt/2, t+Δt — for a lattice that tabulates a smooth closure (PICLES_LATTICE_SMOOTH3)"""
         self._wg = (lat["u"], lat["v"])
         self._ck(self.lib.picles_set_wind_grid(self.h, lat["nx"], lat["ny"], lat["nt"], lat["x0"], lat["dx"], lat["y0"],
                                                lat["dy"], lat["t0"], lat["dt"], K.dptr(lat["u"]), K.dptr(lat["v"]),
                                                mesh_x0, mesh_y0), "picles_set_wind_grid")
+        mode = {"linear": K.LATTICE_LINEAR, "smooth3": K.LATTICE_SMOOTH3}[time_mode]
+        if mode != K.LATTICE_LINEAR:
+            self._ck(self.lib.picles_set_wind_grid_mode(self.h, mode), "picles_set_wind_grid_mode")
 
     def get_winds(self):
         out = [np.empty(self.N) for _ in range(4)]

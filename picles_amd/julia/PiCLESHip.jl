@@ -17,7 +17,7 @@
 # picles_amd/timesteppers.py and picles_amd/simulations.py, which ARE executed against the same C
 # symbols (tests/test_gpu_lazy_state.py: an unobserved 10-step run! loop makes 10 fused launches,
 # <= 1 stand-alone scatter and no State transfer).  Struct layouts mirror include/picles_hip.h
-# field by field (ABI version 3; tests/test_capi_symbols.py holds the struct blocks below against the header).
+# field by field (ABI version 4; tests/test_capi_symbols.py holds the struct blocks below against the header).
 module PiCLESHip
 
 using PiCLES
@@ -29,7 +29,7 @@ import PiCLES.Operators.TimeSteppers: time_step!, movie_time_step!, time_step!_a
 import PiCLES.Simulations: init_particles!
 
 const libpicles = get(ENV, "PICLES_HIP_LIB", "libpicles_hip.so")
-const PICLES_ABI_VERSION = Int32(3)
+const PICLES_ABI_VERSION = Int32(4)
 
 # ---- C structs (include/picles_hip.h) ----------------------------------------------------
 struct picles_grid
@@ -177,7 +177,7 @@ are the keyword arguments that would go to `particle_equations`, because the RHS
 function WaveGrowth2DHIP(; grid::TwoDCartesianGridMesh, winds, ODEsets, γ, q, IDConstants,
         propagation=true, input=true, dissipation=true, peak_shift=true, direction=true,
         ODEinit_type="wind_sea", minimal_state=nothing, periodic_boundary=true,
-        clock, device::Integer=0, winds_static::Bool=false, wind_lattice=nothing)
+        clock, device::Integer=0, winds_static::Bool=false, wind_lattice=nothing, wind_lattice_mode::Symbol=:linear)
     ccall((:picles_abi_version, libpicles), Int32, ()) == PICLES_ABI_VERSION ||
         error("libpicles_hip.so: ABI version mismatch (this binding expects $PICLES_ABI_VERSION)")
     st = grid.stats
@@ -216,6 +216,11 @@ function WaveGrowth2DHIP(; grid::TwoDCartesianGridMesh, winds, ODEsets, γ, q, I
             (Ptr{Cvoid}, Int32, Int32, Int32, Float64, Float64, Float64, Float64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Float64, Float64),
             ctx[], length(x), length(y), length(t), x[1], x[2] - x[1], y[1], y[2] - y[1], t[1], t[2] - t[1],
             u, v, grid.data.x[1, 1], grid.data.y[1, 1]), "picles_set_wind_grid")
+        # time semantics inside a model step (include/picles_hip.h): :linear — the interpolant itself, a time knot inside the step is a
+        # kink the RHS sees (what wind_interpolator's linear_interpolation gives the reference, Utils/WindEmulator.jl:18-43; a step
+        # holding two or more knots is refused); :smooth3 — the lattice tabulates a smooth closure, three levels and the parabola
+        wind_lattice_mode === :smooth3 && check(ctx[], ccall((:picles_set_wind_grid_mode, libpicles), Int32, (Ptr{Cvoid}, Int32),
+            ctx[], Int32(1)), "picles_set_wind_grid_mode")
         model.winds_uploaded = true               # the device samples every step by itself
         model.winds_static = true
     end

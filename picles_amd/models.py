@@ -221,6 +221,26 @@ def wind_window(winds, grid, t, dt, last=None, rows=None, levels=3):
     return u0, v0, um, vm, u1, v1
 
 
+def gridded_wind_window(winds, grid, t, dt, last=None, rows=None):
+    """the same for a GriddedWinds lattice sampled on the HOST (CPU backends; the HIP backend samples its own copy of the lattice on
+    the device and builds the very same windows): returns (u0, v0, um, vm, u1, v1, tk).  time_mode "linear": the interpolant is
+    piecewise linear in t, so a window without a lattice knot inside is two levels, one with a knot inside carries the level AT
+    the knot (tk: two straight segments, picles_set_winds_knot), one with two or more is refused like the library refuses it;
+    "smooth3": three levels at t, t+dt/2, t+dt (tk = None: the parabola)."""
+    from .wind_emulator import lattice_knots
+    if winds.time_mode == "smooth3":
+        return wind_window(winds, grid, t, dt, last, rows, levels=3) + (None,)
+    nk, tk = lattice_knots(float(winds.t[0]), float(winds.dt), t, dt)
+    if nk >= 2:
+        raise K.PiclesError(f"the model step [{t}, {t + dt}] contains two or more time knots of the wind lattice (spacing {winds.dt} s): "
+                            "take model steps no longer than the lattice spacing, or time_mode='smooth3'")
+    u0, v0, _, _, u1, v1 = wind_window(winds, grid, t, dt, last, rows, levels=2)
+    if nk == 0:
+        return u0, v0, None, None, u1, v1, None
+    uk, vk = sample_winds(winds, grid, tk, rows)
+    return u0, v0, uk, vk, u1, v1, tk
+
+
 def _hip_backend(g, p, o, m, mask, **kw):
     from .driver import HipModel
     return HipModel(g, p, o, m, mask=mask, **kw)
@@ -289,13 +309,14 @@ class WaveGrowth2D:
             self._winds_static = bool(all(np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]) for k in (0, 1)))
         return self._winds_static
 
-    def upload_winds(self, t, dt):
-        """node-sample the wind closures for the step [t, t+dt]: three levels (t, t+dt/2, t+dt), interpolated in t by the kernel"""
+    def upload_winds(self, t, dt, seeding=False):
+        """node-sample the wind closures for the step [t, t+dt]: three levels (t, t+dt/2, t+dt), interpolated in t by the kernel.
+        `seeding`: the window is init_particles!'s, which reads its level 0 only (winds at t = 0.0, run.jl:213-215)"""
         from .wind_emulator import GriddedWinds
         if isinstance(self.winds, GriddedWinds) and hasattr(self.backend, "set_wind_grid"):
             if self._wind_window != "device-lattice":      # once: the device samples every step itself
                 g = self.grid
-                self.backend.set_wind_grid(self.winds.lattice(), float(g.data.x[0, 0]), float(g.data.y[0, 0]))
+                self.backend.set_wind_grid(self.winds.lattice(), float(g.data.x[0, 0]), float(g.data.y[0, 0]), time_mode=self.winds.time_mode)
                 self._wind_window = "device-lattice"
             return
         if self._is_static(dt):
@@ -307,15 +328,24 @@ class WaveGrowth2D:
         if self._wind_window == (t, t + dt):
             return
         # the level sampled for the end of the previous step is the start level of this one
-        # gridded winds are linear in t between their knots by definition (Interpolations.linear_interpolation,
-        # Utils/WindEmulator.jl:18-43): two levels are their exact form, and what the device-side sampler hands the kernels
-        levels = 2 if isinstance(self.winds, GriddedWinds) else self.wind_time_levels
-        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), levels=levels)
+        tk = None
+        if isinstance(self.winds, GriddedWinds):
+            # a lattice sampled on the host (CPU backends): the interpolant is piecewise linear in t (Interpolations.linear_interpolation,
+            # Utils/WindEmulator.jl:18-43) — two levels where no time knot falls inside the step, the level at the knot where one does
+            if seeding:
+                u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, None, levels=2)
+            else:
+                u0, v0, um, vm, u1, v1, tk = gridded_wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None))
+        else:
+            u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), levels=self.wind_time_levels)
         if um is None:
             self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
-        else:
+        elif tk is None:
             self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm)
-        self._wind_window = (t, t + dt)
+        else:
+            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm, tk=tk)
+        # (the seeding window of a lattice is not a step's window: a knot inside it was not looked for)
+        self._wind_window = None if (seeding and isinstance(self.winds, GriddedWinds)) else (t, t + dt)
         self._wind_last = (t + dt, u1, v1)
 
     # ---- State lives on the device ----

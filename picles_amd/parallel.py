@@ -21,7 +21,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi as K
-from .models import build_structs, sample_winds, wind_window
+from .models import build_structs, sample_winds, wind_window, gridded_wind_window
 
 
 def slab_rows(Ny: int, world: int, rank: int):
@@ -298,13 +298,14 @@ class SlabModel:
             n += int((mk == 3).sum())
         return n
 
-    def upload_winds(self, t, dt):
+    def upload_winds(self, t, dt, seeding=False):
         rows = (self.j0, self.j1)
         from .wind_emulator import GriddedWinds
         if isinstance(self.winds, GriddedWinds) and hasattr(self.backend, "set_wind_grid"):
             if self._wind_window != "device-lattice":      # once: every slab samples its own rows on the device
                 g = self.grid
-                self.backend.set_wind_grid(self.winds.lattice(), float(g.data.x[0, 0]), float(g.data.y[0, 0]))   # global mesh origin: the sampler adds j_begin
+                self.backend.set_wind_grid(self.winds.lattice(), float(g.data.x[0, 0]), float(g.data.y[0, 0]),   # global mesh origin: the sampler adds j_begin
+                                           time_mode=self.winds.time_mode)
                 self._wind_window = "device-lattice"
             return
         if self.static:
@@ -313,17 +314,26 @@ class SlabModel:
                 self.backend.set_winds(u, v, t)
                 self._wind_window = (t, t)
             return
-        levels = 2 if isinstance(self.winds, GriddedWinds) else getattr(self, "wind_time_levels", 3)      # see models.upload_winds
-        u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), rows, levels=levels)
+        tk = None
+        if isinstance(self.winds, GriddedWinds):       # host-sampled lattice (CPU backends): see models.upload_winds
+            if seeding:     # init_particles! reads level 0 only
+                u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, None, rows, levels=2)
+            else:
+                u0, v0, um, vm, u1, v1, tk = gridded_wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), rows)
+        else:
+            u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), rows,
+                                                 levels=getattr(self, "wind_time_levels", 3))
         if um is None:
             self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
-        else:
+        elif tk is None:
             self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm)
+        else:
+            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm, tk=tk)
         self._wind_last = (t + dt, u1, v1)
 
     def seed(self):
         self._wind_window = None
-        self.upload_winds(0.0, self.timestep)
+        self.upload_winds(0.0, self.timestep, seeding=True)
         self.backend.seed(0.0)
         self.backend.sync()        # the seed kernel runs on the context stream, the steps on s_edge / s_main
         if self.native and not getattr(self, "_comm_warm", False):

@@ -57,7 +57,7 @@ def init_particles(model, defaults=None, verbose=False):
     """init_particles!(model) (run.jl:199-247): seed every node from the winds at t = 0 with the
     time scale ODEsettings.timestep, write the seeds' (e, m_x, m_y) into State."""
     model._wind_window = None
-    model.upload_winds(0.0, model.ODEsettings.timestep)
+    model.upload_winds(0.0, model.ODEsettings.timestep, seeding=True)
     model.backend.seed(model.clock.time)
 
 

@@ -4,7 +4,8 @@
 knots `x, y, t` and lattices `u, v` [nx, ny, nt] and returns an object whose `.u(x,y,t)` / `.v(x,y,t)`
 are tri-linear interpolants with periodic continuation (Interpolations.linear_interpolation(...,
 extrapolation_bc = Periodic())).  Handed to WaveGrowth2D as `winds=`, the lattice is uploaded to HBM once
-(`picles_set_wind_grid`) and every step samples its two time levels on the device; the NumPy evaluation
+(`picles_set_wind_grid`) and every step samples its time levels on the device (two, or three when a time knot of the
+lattice falls inside the step); the NumPy evaluation
 below performs the same arithmetic in the same order and is what a CPU backend / the tests use.
 """
 from __future__ import annotations
@@ -22,8 +23,28 @@ def _lattice_coord(c, n):
     return i0, w - i0.astype(np.float64)
 
 
+def lattice_knots(lat_t0, lat_dt, t, dt):
+    """time knots of a regular lattice strictly inside the window (t, t + dt): (count capped at 2, time of the first one) — the same
+    arithmetic as the library's picles_lattice_knots (tests hold the two against each other).  A knot closer to either end of the
+    window than 1e-9 lattice intervals counts as that end."""
+    eps = 1e-9
+    c0, c1 = (t - lat_t0) / lat_dt, (t + dt - lat_t0) / lat_dt
+    k0 = float(np.floor(c0 + eps)) + 1.0
+    if not (k0 < c1 - eps):
+        return 0, None
+    return (2 if k0 + 1.0 < c1 - eps else 1), lat_t0 + k0 * lat_dt
+
+
 class GriddedWinds:
-    def __init__(self, x, y, t, u, v):
+    """time_mode "linear": the model follows the interpolant itself inside a step, kinks at the lattice's time knots included —
+    what the reference does when its winds come from wind_interpolator (the RHS evaluates linear_interpolation((x,y,t), u) at
+    every stage time, particle_waves_v5.jl:494-495).  "smooth3": the lattice tabulates a smooth closure (knots at Δt/2 or
+    finer); the step follows the parabola through its samples at t, t+Δt/2, t+Δt."""
+
+    def __init__(self, x, y, t, u, v, time_mode="linear"):
+        if time_mode not in ("linear", "smooth3"):
+            raise ValueError("time_mode must be 'linear' or 'smooth3'")
+        self.time_mode = time_mode
         self.x, self.y, self.t = (np.asarray(a, dtype=np.float64) for a in (x, y, t))
         for a, name in ((self.x, "x"), (self.y, "y"), (self.t, "t")):
             if a.size < 2 or not np.allclose(np.diff(a), a[1] - a[0], rtol=1e-12, atol=0):
@@ -63,10 +84,10 @@ class GriddedWinds:
                     v=np.ascontiguousarray(self.vg.reshape(-1, order="F")))
 
 
-def wind_interpolator(wind_grid) -> GriddedWinds:
+def wind_interpolator(wind_grid, time_mode="linear") -> GriddedWinds:
     """WindEmulator.jl:18-43 (2D form: knots x, y, t and lattices u, v)"""
     g = wind_grid if isinstance(wind_grid, dict) else vars(wind_grid)
-    return GriddedWinds(g["x"], g["y"], g["t"], g["u"], g["v"])
+    return GriddedWinds(g["x"], g["y"], g["t"], g["u"], g["v"], time_mode=time_mode)
 
 
 def IdealizedWindGrid(u_func, v_func, dims, steps) -> dict:

@@ -37,6 +37,7 @@ def lib(kind: str = "libm") -> C.CDLL:
         "picles_oracle_set_threads": (C.c_int32, [VP, C.c_int32]),
         "picles_oracle_set_winds": (C.c_int32, [VP, DP, DP, D, DP, DP, D]),
         "picles_oracle_set_winds3": (C.c_int32, [VP, DP, DP, D, DP, DP, DP, DP, D]),
+        "picles_oracle_set_winds_knot": (C.c_int32, [VP, DP, DP, D, DP, DP, D, DP, DP, D]),
         "picles_oracle_seed": (C.c_int32, [VP, D]),
         "picles_oracle_advance": (C.c_int32, [VP, D]),
         "picles_oracle_remesh": (C.c_int32, [VP, D]),
@@ -137,7 +138,7 @@ class OracleModel:
             pass
 
     # --- same names as the product driver ---
-    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0, um=None, vm=None):
+    def set_winds(self, u0, v0, t0=0.0, u1=None, v1=None, t1=0.0, um=None, vm=None, tk=None):
         def col(a):
             a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, order="F"))
             assert a.size == self.N, (a.size, self.N)
@@ -147,6 +148,10 @@ class OracleModel:
             u1, v1 = col(u1), col(v1)
         if um is not None:
             um, vm = col(um), col(vm)
+        if tk is not None:
+            rc = self.L.picles_oracle_set_winds_knot(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(um), K.dptr(vm), float(tk), K.dptr(u1), K.dptr(v1), t1)
+            assert rc == 0, rc
+            return
         self.L.picles_oracle_set_winds3(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(um), K.dptr(vm), K.dptr(u1), K.dptr(v1), t1)
 
     def set_metric(self, m11, m22, pc):

@@ -3,7 +3,8 @@
 
 Plain NumPy + SciPy restatement of one `time_step!` of the reference on a small NON-uniform case —
 24×20 mesh, periodic in x / open in y, a land block, spatially (and, in one case, temporally) varying
-winds with a calm band — written from the reference's Julia sources alone.  Nothing here imports
+winds with a calm band (closures, or a gridded lattice whose time knots fall inside the model steps) — written from the
+reference's Julia sources alone.  Nothing here imports
 `oracle/`, `picles_amd/` or the HIP library; the tests then hold oracle A (libm, literal order), oracle B
 (pmath, kernel order) and the HIP path against these files.
 
@@ -16,6 +17,7 @@ What is restated (reference file:line):
   ParticleToNode!/push_to_grid!  src/Operators/mapping_2D.jl:59-73, src/ParticleInCell.jl:58-71,341-376,444-466,504-508
   NodeToParticle! (A-D)          src/Operators/mapping_2D.jl:279-356, src/Operators/core_2D.jl:69-78,121-128
   time_step!, run! zeroing       src/Operators/TimeSteppers.jl:109-166, src/Simulations/run.jl:72-114
+  wind_interpolator (gridded)    src/Utils/WindEmulator.jl:18-43
 
 `step!(integrator, DT, true)` (OrdinaryDiffEq, third-party, not in the reference tree) is replaced by the
 CONVERGED solution: scipy `solve_ivp(DOP853, rtol 1e-12, atol 1e-14)`.  A tolerance-respecting stepper
@@ -258,9 +260,13 @@ class Model:
         if self.on[i, j]:
             f = make_rhs(lambda t: self.wind(i, j, t)[0], lambda t: self.wind(i, j, t)[1], self.idc, self.C_alpha,
                          self.C_phi, self.m11[i, j], self.m22[i, j], self.sw, pc=self.pc[i, j])
-            sol = solve_ivp(f, (t0, t0 + DT), z, method="DOP853", rtol=1e-12, atol=1e-14)
-            assert sol.success
-            z = [float(a) for a in sol.y[:, -1]]
+            # a forcing with kinks at known times (a gridded wind's time knots) is integrated segment by segment: the converged
+            # solution of the same ODE, without asking a high-order method to step across a discontinuous derivative
+            brk = [t0] + [tk for tk in getattr(self.winds[0], "t_knots", ()) if t0 < tk < t0 + DT] + [t0 + DT]
+            for ta, tb in zip(brk[:-1], brk[1:]):
+                sol = solve_ivp(f, (ta, tb), z, method="DOP853", rtol=1e-12, atol=1e-14)
+                assert sol.success
+                z = [float(a) for a in sol.y[:, -1]]
         else:
             w = self.wind(i, j, t0 + DT)
             if w[0] ** 2 + w[1] ** 2 >= self.wind_min_sq:
@@ -333,6 +339,60 @@ def winds_space(dx, dy, U=11.0, V=6.0, tfac=None):
     return u, v
 
 
+# ---------------------------------------------------------------- Utils/WindEmulator.jl:18-43
+class LatticeWind:
+    """one component of wind_interpolator(wind_grid): Interpolations.linear_interpolation((x, y, t), F; extrapolation_bc = Periodic())
+    on a regular lattice — tri-linear inside a cell, piecewise linear along every axis, kinks at the knots.  The RHS of the reference
+    calls it at every stage time (particle_waves_v5.jl:494-495): a time knot inside a model step is a kink the solver sees."""
+
+    def __init__(self, xk, yk, tk, F):
+        self.xk, self.yk, self.tk, self.F = (np.asarray(a, dtype=np.float64) for a in (xk, yk, tk, F))
+        self.t_knots = tuple(float(t) for t in self.tk)
+        self._series = {}
+
+    @staticmethod
+    def _cell(c, knots):
+        h = knots[1] - knots[0]
+        per = knots[-1] - knots[0]
+        w = (c - knots[0]) % per if (c < knots[0] or c > knots[-1]) else c - knots[0]      # Periodic(): period = last - first knot
+        i = min(int(math.floor(w / h)), len(knots) - 2)
+        return i, w / h - i
+
+    def series(self, x, y):
+        """the node's wind at every time knot (bilinear in x, y)"""
+        key = (float(x), float(y))
+        if key not in self._series:
+            i, fx = self._cell(float(x), self.xk)
+            j, fy = self._cell(float(y), self.yk)
+            F = self.F
+            self._series[key] = ((F[i, j] * (1 - fx) + F[i + 1, j] * fx) * (1 - fy) + (F[i, j + 1] * (1 - fx) + F[i + 1, j + 1] * fx) * fy)
+        return self._series[key]
+
+    def __call__(self, x, y, t):
+        s = self.series(x, y)
+        k, ft = self._cell(float(t), self.tk)
+        return s[k] * (1 - ft) + s[k + 1] * ft
+
+
+def winds_lattice(dx, dy, lat_dt, T_end, U=11.0, V=6.0, amp_t=0.08):
+    """a wind lattice coarser than the mesh (3 x 2 mesh cells per lattice cell) whose time series zig-zags by 8-16 % from knot to
+    knot: a window that ignores a knot inside a model step is wrong by several per cent of the wind there"""
+    u0, v0 = winds_space(dx, dy, U=U, V=V)
+    xk = np.arange(0.0, NX * dx + 1.0, 3 * dx)                # 0 .. Lx (the mesh ends one cell short of Lx: periodic)
+    yk = np.arange(0.0, (NY - 1) * dy + 2 * dy, 2 * dy)       # covers 0 .. Ly
+    tk = np.arange(0.0, T_end + 0.5 * lat_dt, lat_dt)
+    # (amplitude chosen so that the tolerance-respecting steppers (abstol 1e-4, reltol 1e-3) still sit within the stated 1e-3 of the
+    # converged solution: a zig-zag of +-30 % is followed to 3e-3 only, and flips remesh branches at single nodes)
+    zu = np.array([0.0, 1.0, -0.7, 0.9, -1.0, 0.7, -0.4, 1.0, -0.6, 0.4, -0.9, 1.0, 0.0, 0.7, -0.7])[:tk.size]
+    zv = np.array([0.0, -0.7, 0.6, -0.9, 0.8, -0.4, 1.0, -1.0, 0.4, -0.6, 0.9, -0.7, 0.0, -0.4, 0.7])[:tk.size]
+    gu, gv = 1.0 + amp_t * zu, 1.0 + amp_t * zv
+    assert gu.size == tk.size
+    X, Y = np.meshgrid(xk, yk, indexing="ij")
+    Fu = u0(X, Y, 0.0)[:, :, None] * gu[None, None, :]
+    Fv = v0(X, Y, 0.0)[:, :, None] * gv[None, None, :]
+    return LatticeWind(xk, yk, tk, Fu), LatticeWind(xk, yk, tk, Fv)
+
+
 ALL_ON = dict(propagation=True, input=True, dissipation=True, peak_shift=True, direction=True)
 CASES = {
     # exact ODE (translation only): pins scatter / wrap / drop / remesh branches to rounding; reach up to 2 cells
@@ -354,6 +414,17 @@ CASES = {
     # of the stated tolerance: it measures what the three-level window of the boundary costs when the forcing is that fast
     "full_tvar_fast": dict(dx=2000.0, dy=2500.0, DT=1200.0, timestep=1200.0, C_phi=1.81e-5, periodic_boundary=False,
                            lne_max=math.log(27), sw=ALL_ON, tfac=lambda t: 0.6 + 0.4 * math.cos(2 * math.pi * t / 4800.0)),
+    # GRIDDED winds (wind_interpolator, Utils/WindEmulator.jl:18-43) whose time knots do NOT line up with the model steps: 900-second
+    # knots under 10-minute steps (every second step has a knot in its middle), the lattice's own piecewise-linear interpolant
+    # evaluated at the solver's times
+    "full_lattice_900": dict(dx=2000.0, dy=2500.0, DT=600.0, timestep=600.0, C_phi=1.81e-5, periodic_boundary=False,
+                             lne_max=math.log(27), sw=ALL_ON, tfac=None, lattice_dt=900.0),
+    # 600-second knots under the 20-minute step of BASELINE config 5: every step has a knot at its middle
+    "full_lattice_600_dt1200": dict(dx=2000.0, dy=2500.0, DT=1200.0, timestep=1200.0, C_phi=1.81e-5, periodic_boundary=False,
+                                    lne_max=math.log(27), sw=ALL_ON, tfac=None, lattice_dt=600.0),
+    # 700-second knots under 10-minute steps: the knot wanders through the step (s = 1/6, 1/3, 1/2, 2/3, 5/6, none)
+    "full_lattice_700": dict(dx=2000.0, dy=2500.0, DT=600.0, timestep=600.0, C_phi=1.81e-5, periodic_boundary=False,
+                             lne_max=math.log(27), sw=ALL_ON, tfac=None, lattice_dt=700.0),
 }
 STEPS = (1, 3, 6)
 
@@ -391,7 +462,10 @@ def build(name):
         return Model(NX, NY, 1.0, 1.0, True, False, ocean_mask(), sphere_winds(), c["periodic_boundary"], c["C_phi"], c["sw"],
                      c["DT"], c["timestep"], c["lne_max"], mesh=mesh, defaults=sphere_defaults())
     c = CASES[name]
-    u, v = winds_space(c["dx"], c["dy"], tfac=c["tfac"])
+    if c.get("lattice_dt"):
+        u, v = winds_lattice(c["dx"], c["dy"], c["lattice_dt"], 6 * c["DT"] + 2 * c["lattice_dt"])
+    else:
+        u, v = winds_space(c["dx"], c["dy"], tfac=c["tfac"])
     return Model(NX, NY, c["dx"], c["dy"], True, False, ocean_mask(), (u, v), c["periodic_boundary"], c["C_phi"], c["sw"],
                  c["DT"], c["timestep"], c["lne_max"])
 
@@ -412,6 +486,8 @@ def main():
                 out[f"margin{k}"] = m.margin.copy()
                 out[f"z{k}"] = m.z.copy()                # particles after the remesh of step k
             print(name, k, "sum e", S[..., 0].sum(), "on", int(m.on.sum()), "max reach", int(np.abs(m.cell).max() + 1), flush=True)
+        if isinstance(m.winds[0], LatticeWind):     # the lattice itself travels with the fixture (data: knots and node values)
+            out.update(lat_x=m.winds[0].xk, lat_y=m.winds[0].yk, lat_t=m.winds[0].tk, lat_u=m.winds[0].F, lat_v=m.winds[1].F)
         np.savez_compressed(HERE / f"step2d_{name}.npz", **out)
 
 

@@ -115,7 +115,10 @@ def test_rk_loops_stay_clear_of_spill_code():
     assert base == (0, 0), base
     for name, (scr, lane) in ex.items():
         if name.startswith("_Z6k_stepILb1E"):                     # specialised physics, four waves per SIMD
-            assert lane <= 4, (name, scr, lane)
+            # (the time-varying-wind flavours carry the knot position of a gridded wind's window through the loop since round 4:
+            # one more scalar pair, two more lane moves per loop body in the Tsit5 one — 0.2 % of an attempt's 985 instructions)
+            static = "ILb1ELb0ELb1E" in name or "ILb1ELb1ELb1E" in name
+            assert lane <= (4 if static else 6), (name, scr, lane)
             if "ILb1ELb0ELb1ELb0E" in name or "ILb1ELb1ELb1ELb0E" in name:      # static winds, Cartesian: DP5 and Tsit5
                 assert scr <= 4, (name, scr)
     au = _rk_loop_spills("k_step_auto.hip")
@@ -135,7 +138,8 @@ def test_stand_alone_advance_reloads_its_arguments_in_every_flavour():
         if not name.startswith("_Z9k_advance"):
             continue
         general_auto = name.startswith("_Z9k_advanceILb0E") and name.split("EEv")[0].endswith("ELb1")
-        assert u["sspill"] <= (110 if general_auto else 20), (name, u)
+        # (24, not 20: the general-physics time-varying flavours keep the knot position of a gridded wind's window since round 4: 22)
+        assert u["sspill"] <= (110 if general_auto else 24), (name, u)
         assert u["scratch"] <= 96, (name, u)
 
 

@@ -1,11 +1,16 @@
 """Gridded wind ingestion (Utils/WindEmulator.jl:18-43): NumPy restatement of the
 tri-linear + periodic interpolant (CPU) and, on the GPU, the device sampler against it — bitwise —
-plus a full run driven by device-sampled winds against the oracle driven by host-sampled winds."""
+plus full runs driven by device-sampled winds against the oracle driven by host-sampled winds.
+The lattice below has 900-second time knots under 600-second model steps: every second step has a knot
+in its middle, which the window carries as a third level AT the knot (two straight segments); the
+independent fixtures that pin this semantics are tests/golden/step2d_full_lattice_*.npz
+(tests/test_step2d_fixture.py)."""
 import numpy as np
 import pytest
 
 from picles_amd import configs
-from picles_amd.wind_emulator import wind_interpolator, IdealizedWindGrid
+from picles_amd import _capi as K
+from picles_amd.wind_emulator import wind_interpolator, IdealizedWindGrid, lattice_knots
 from picles_amd.simulations import Simulation, initialize_simulation
 from picles_amd.timesteppers import time_step
 from helpers import make_model, assert_bitwise
@@ -30,6 +35,39 @@ def test_interpolant_hits_knots_and_is_periodic():
     a = w.v(np.array([7.3e3]), np.array([9e3]), 1000.0)
     b = w.v(np.array([7.3e3 + Lx]), np.array([9e3]), 1000.0 + 7200.0)
     assert a[0] == pytest.approx(b[0], rel=1e-12)
+
+
+def test_knot_classifier_python_and_c_agree():
+    """wind_emulator.lattice_knots (host-sampled windows of the CPU backends) against picles_lattice_knots (the library's own
+    windows): same counts, same knot times to the bit, on aligned, misaligned and nearly-aligned windows"""
+    import ctypes as C
+    lib = K.load()
+    rng = np.random.default_rng(7)
+    cases = [(0.0, 900.0, 600.0 * k, 600.0) for k in range(12)] + [(0.0, 600.0, 1200.0 * k, 1200.0) for k in range(6)] + \
+            [(0.0, 600.0, 1800.0 * k, 1800.0) for k in range(3)] + [(-300.0, 700.0, 600.0 * k, 600.0) for k in range(20)] + \
+            [(0.0, 0.1 * 9000, 0.1 * 6000 * k, 0.1 * 6000) for k in range(9)] + \
+            [(float(rng.uniform(-1e4, 1e4)), float(rng.uniform(50, 5e3)), float(rng.uniform(0, 1e5)), float(rng.uniform(10, 4e3))) for _ in range(300)]
+    seen = set()
+    for t0, ldt, t, dt in cases:
+        tk = C.c_double(-1.0)
+        n = lib.picles_lattice_knots(t0, ldt, t, dt, C.byref(tk))
+        npy, tkp = lattice_knots(t0, ldt, t, dt)
+        assert n == npy, (t0, ldt, t, dt, n, npy)
+        if n:
+            assert tk.value == tkp and t < tkp < t + dt
+        seen.add(n)
+    assert seen == {0, 1, 2}
+    # 600-second steps against 900-second knots: the window [1200, 1800] ends ON a knot — not inside it
+    assert lattice_knots(0.0, 900.0, 1200.0, 600.0)[0] == 0 and lattice_knots(0.0, 900.0, 600.0, 600.0) == (1, 900.0)
+
+
+def test_host_sampled_window_refuses_two_knots_in_one_step():
+    lat, _, _ = _lattice()
+    w = wind_interpolator(lat)
+    o = make_model(_cfg(w), ("pmath", 1))
+    initialize_simulation(Simulation(o, Δt=2000.0, stop_time=1.0))       # seeding looks at level 0 only: no refusal there
+    with pytest.raises(K.PiclesError, match="two or more time knots"):
+        time_step(o, 2000.0, zero_first=True)                            # [0, 2000] holds the knots at 900 and 1800
 
 
 def _cfg(w):
@@ -59,6 +97,49 @@ def test_device_sampler_bitwise_and_run_matches_oracle():
     u0, v0, u1, v1 = g.backend.get_winds()
     assert_bitwise(u0, w.u(X, Y, 2400.0), "u0 of the last step")
     assert_bitwise(u1, w.u(X, Y, 3000.0), "u1 of the last step")
+    # the last step [2400, 3000] holds the knot at 2700: its level is on the device, sampled AT the knot
+    um, vm = g.backend.get_winds_mid()
+    assert_bitwise(um, w.u(X, Y, 2700.0), "u at the knot inside the last step")
+    assert_bitwise(vm, w.v(X, Y, 2700.0), "v at the knot inside the last step")
+
+
+@pytest.mark.gpu
+def test_device_lattice_refuses_a_step_with_two_knots_and_stays_usable():
+    lat, _, _ = _lattice()
+    w = wind_interpolator(lat)
+    g = make_model(_cfg(w), "hip")
+    o = make_model(_cfg(w), ("pmath", 1))
+    for m in (g, o):
+        initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
+    with pytest.raises(K.PiclesError, match="two or more time knots"):
+        time_step(g, 2000.0, zero_first=True)
+    for k in range(3):           # the refused step changed nothing: the run continues bit for bit
+        for m in (g, o):
+            time_step(m, 600.0, zero_first=True)
+    assert_bitwise(g.State, o.State, "State after a refused step")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["DP5", "AutoTsit5"])
+def test_smooth3_mode_samples_three_levels_on_the_device(solver):
+    """PICLES_LATTICE_SMOOTH3: the lattice as the carrier of a smooth closure — levels at t, t+Δt/2, t+Δt sampled on the device, the
+    parabola through them; bitwise equal to the oracle fed the same three host-sampled levels"""
+    lat, _, _ = _lattice()
+    def mk():
+        c = _cfg(wind_interpolator(lat, time_mode="smooth3"))
+        c.model["ODEsets"].solver = solver
+        return c
+    g, o = make_model(mk(), "hip"), make_model(mk(), ("pmath", 1))
+    for m in (g, o):
+        initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
+    w = g.winds
+    X, Y = g.grid.data.x, g.grid.data.y
+    for k in range(4):
+        for m in (g, o):
+            time_step(m, 600.0, zero_first=True)
+    assert_bitwise(g.State, o.State, "State, smooth3")
+    um, vm = g.backend.get_winds_mid()
+    assert_bitwise(um, w.u(X, Y, 1800.0 + 300.0), "u at mid-step")
 
 
 def _calm_lattice():
@@ -71,8 +152,9 @@ def _calm_lattice():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["Tsit5", "AutoTsit5"])
 @pytest.mark.parametrize("lattice", ["smooth", "calm_band"])
-def test_unobserved_run_under_device_sampled_winds_is_fused_and_matches_oracle(lattice):
+def test_unobserved_run_under_device_sampled_winds_is_fused_and_matches_oracle(lattice, solver):
     """consecutive run!-style steps with NOBODY looking at State in between: the library rotates three wind level
     planes and runs one fused launch per step (k_step, time-varying flavour) whose remesh reads the wind of the
     previous window.  Final State, particles and counters must equal the step-by-step oracle bitwise."""
@@ -80,7 +162,8 @@ def test_unobserved_run_under_device_sampled_winds_is_fused_and_matches_oracle(l
     w = wind_interpolator(lat)
     def mk():
         c = _cfg(w)
-        c.model["ODEsets"].solver = "Tsit5"        # the explicit pairs run fused; the default (auto-switching) solver does not
+        c.model["ODEsets"].solver = solver         # the explicit pairs and the default (auto-switching) solver all run fused
+                                                   # under device winds (k_step<1,1,0,0,0> / k_step<1,1,0,0,1>)
         return c
     g = make_model(mk(), "hip")
     o = make_model(mk(), ("pmath", 1))
