@@ -304,6 +304,20 @@ int32_t picles_slab_run_steps(picles_ctx *ctx, double dt, int32_t n_steps, int32
 int32_t picles_slab_exchange(picles_ctx *ctx);        /* one synchronous halo exchange of the current records (warm-up of the RCCL channels) */
 int32_t picles_slab_streams(picles_ctx *ctx, void **edge_stream, void **interior_stream);   /* hipStream_t of the ring (timing, profiling) */
 int32_t picles_slab_comm_destroy(picles_ctx *ctx);
+/* Where a ring step's time goes, from HIP events the ring records on its two streams while picles_enable_timing(ctx, 1) is on
+ * (five per step): sums over the steps since the last call.  The diagnosis of a multi-GPU run in one look: the edge launch, the
+ * exchange behind it (ncclGroup of the halo blocks, on the edge stream), the interior launch (other stream), and whether the
+ * exchange had completed when the interior launch ended (it then cost nothing).  Syncs the device; clears the sums. */
+typedef struct picles_slab_phases {
+    uint64_t steps;            /* ring steps measured                                                          */
+    uint64_t exchange_hidden;  /* ... of which the exchange had completed before the interior launch ended      */
+    double   edge_ms;          /* edge-row launches (stream E)                                                  */
+    double   exchange_ms;      /* end of the edge launch -> end of the send/recv group (stream E)               */
+    double   interior_ms;      /* interior launches (stream M)                                                  */
+    double   slack_ms;         /* interior end - exchange end, summed: > 0 = the exchange finished first        */
+    double   span_ms;          /* edge begin -> the later of exchange end and interior end, summed              */
+} picles_slab_phases;
+int32_t picles_slab_get_phases(picles_ctx *ctx, picles_slab_phases *out);
 
 /* ---- generic particle->mesh scatter of an arbitrary particle list --------------
  * (ParticleInCell.push_to_grid! over a list, ParticleInCell.jl:341-376,530-538):

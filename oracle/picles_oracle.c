@@ -450,27 +450,29 @@ static inline void po_wind(const po_model *M, int64_t idx, double t, double *u, 
             *v = M->v0[idx] + (M->v1[idx] - M->v0[idx]) * s;
         }
     } else {
-        /* kernel order (physics.h, wind_shape / wind_eval; kernels.h, load_wind): u0 + s du + g(s) bu with g = s (s - 1) and the
-         * Newton coefficients of the parabola, or g = max(s - sk, 0) with the first segment's slope du = (uk - u0)/sk and the jump
-         * of the slope bu = (u1 - uk)/(1 - sk) - du */
+        /* kernel order (physics.h, wind_eval2; kernels.h, load_wind): the parabola in Newton form, u0 + s (du + (s - 1) bu) with
+         * bu = 2 ((u0 + u1) - 2 um) (two levels: bu = 0), or the knot form u0 + s du + max(s - sk, 0) bu with the first segment's
+         * slope du = (uk - u0)/sk and the jump of the slope bu = (u1 - uk)/(1 - sk) - du */
         const double idt = 1.0 / (M->tw1 - M->tw0);
         double s = (t - M->tw0) * idt;
-        double du = M->u1[idx] - M->u0[idx], dv = M->v1[idx] - M->v0[idx], bu = 0.0, bv = 0.0, g;
         if (M->um && M->wind_knot) {
             const double sk = (M->twk - M->tw0) * idt, isk = 1.0 / sk, i1sk = 1.0 / (1.0 - sk);
-            du = (M->um[idx] - M->u0[idx]) * isk; dv = (M->vm[idx] - M->v0[idx]) * isk;
-            bu = (M->u1[idx] - M->um[idx]) * i1sk - du; bv = (M->v1[idx] - M->vm[idx]) * i1sk - dv;
+            const double du = (M->um[idx] - M->u0[idx]) * isk, dv = (M->vm[idx] - M->v0[idx]) * isk;
+            const double bu = (M->u1[idx] - M->um[idx]) * i1sk - du, bv = (M->v1[idx] - M->vm[idx]) * i1sk - dv;
             double sp = s - sk;
-            g = (sp > 0.0) ? sp : 0.0;
-        } else {
-            if (M->um) {
-                bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
-                bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
-            }
-            g = s * (s - 1.0);
+            sp = (sp > 0.0) ? sp : 0.0;
+            *u = PO_FMA(bu, sp, PO_FMA(du, s, M->u0[idx]));
+            *v = PO_FMA(bv, sp, PO_FMA(dv, s, M->v0[idx]));
+            return;
         }
-        *u = PO_FMA(bu, g, PO_FMA(du, s, M->u0[idx]));
-        *v = PO_FMA(bv, g, PO_FMA(dv, s, M->v0[idx]));
+        double s1 = s - 1.0;
+        double bu = 0.0, bv = 0.0;
+        if (M->um) {
+            bu = 2.0 * ((M->u0[idx] + M->u1[idx]) - 2.0 * M->um[idx]);
+            bv = 2.0 * ((M->v0[idx] + M->v1[idx]) - 2.0 * M->vm[idx]);
+        }
+        *u = PO_FMA(PO_FMA(bu, s1, M->u1[idx] - M->u0[idx]), s, M->u0[idx]);
+        *v = PO_FMA(PO_FMA(bv, s1, M->v1[idx] - M->v0[idx]), s, M->v0[idx]);
     }
 }
 

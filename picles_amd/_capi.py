@@ -86,6 +86,17 @@ class PiclesTiming(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class PiclesSlabPhases(C.Structure):
+    _fields_ = [
+        ("steps", C.c_uint64), ("exchange_hidden", C.c_uint64),
+        ("edge_ms", C.c_double), ("exchange_ms", C.c_double), ("interior_ms", C.c_double),
+        ("slack_ms", C.c_double), ("span_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 LATTICE_LINEAR, LATTICE_SMOOTH3 = 0, 1
 STEP_ZERO_FIRST = 1
 STEP_MOVIE = 2
@@ -158,6 +169,7 @@ SYMBOLS = {
     "picles_slab_exchange": (C.c_int32, [_VP]),
     "picles_slab_streams": (C.c_int32, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
     "picles_slab_comm_destroy": (C.c_int32, [_VP]),
+    "picles_slab_get_phases": (C.c_int32, [_VP, C.POINTER(PiclesSlabPhases)]),
     "picles_scatter_particles": (C.c_int32, [_VP, C.c_int64, c_int32_p, c_double_p, c_double_p]),
 }
 

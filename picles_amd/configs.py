@@ -147,6 +147,40 @@ def growing_decaying_winds(n=2048, dx=2000.0, U10=10.0, V10=10.0, n_steps=60):
         Δt=DT, n_steps=n_steps, mode="run")
 
 
+def closure_lattice(cfg, n_steps, x=None, y=None, knots_per_step=2):
+    """carry a config's wind closures as a device lattice in SMOOTH3 mode (picles_set_wind_grid_mode): the closures are tabulated
+    once — time knots `knots_per_step` per model step (2: at Δt/2, so that every level the device samples, t, t+Δt/2 and t+Δt, is
+    a knot = an exact sample of the closure), lattice knots `x`, `y` (default: the mesh's own nodes, where the spatial
+    interpolation is the identity) — and every step follows the parabola through three device-sampled levels: the accuracy of
+    the three-level closure path (picles_set_winds3) with no host work and no wind traffic over PCIe in the time loop."""
+    from .wind_emulator import wind_interpolator
+    g = cfg.model["grid"]
+    x = g.data.x[:, 0] if x is None else np.asarray(x, dtype=np.float64)
+    y = g.data.y[0, :] if y is None else np.asarray(y, dtype=np.float64)
+    dtk = cfg.Δt / knots_per_step
+    t = np.arange(0.0, (n_steps + 2) * cfg.Δt + 0.5 * dtk, dtk)
+    X, Y, T = np.meshgrid(x, y, t, indexing="ij")
+    def tab(f):        # closures written for scalars (math.cos ...) are evaluated knot by knot
+        try:
+            return np.asarray(f(X, Y, T), dtype=np.float64) + 0 * X
+        except TypeError:
+            return np.vectorize(lambda a, b, c: float(f(a, b, c)), otypes=[np.float64])(X, Y, T)
+    w = wind_interpolator(dict(x=x, y=y, t=t, u=tab(cfg.model["winds"].u), v=tab(cfg.model["winds"].v)), time_mode="smooth3")
+    cfg.model["winds"] = w
+    cfg.model["ODEsys"].u, cfg.model["ODEsys"].v = w.u, w.v
+    cfg.model["winds_static"] = False
+    return cfg
+
+
+def growing_decaying_winds_lattice(n=2048, n_steps=60, **kw):
+    """BASELINE config 5 with its forcing A(x)·f(t) as a device lattice: node resolution in x (the ramp has a kink at L/2), two
+    knots in y (the forcing does not depend on y), time knots at Δt/2, SMOOTH3 — the conformant device path of config 5
+    (tests/test_step2d_fixture.py::test_config5_forcing_through_a_smooth3_lattice holds the same construction to the fixture)"""
+    cfg = growing_decaying_winds(n=n, n_steps=n_steps, **kw)
+    g = cfg.model["grid"]
+    return closure_lattice(cfg, n_steps, y=np.array([0.0, float(g.data.y[0, -1])]))
+
+
 def sphere_aqua(nx=91, ny=61, n_steps=8, with_land=True):
     """tests/T03_PIC_sphere_aqua.jl:36-175 — lon/lat mesh 0..180° × 0..80° (periodic in lon), Gaussian
     wind blob (-20, 1) m/s centred at (90°, 40°), Δt = 120 min, fixed default particle, C_φ = c_β,

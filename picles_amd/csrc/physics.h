@@ -216,10 +216,10 @@ struct Vec5 {
     double lne, cx, cy, x, y;
 };
 
-/* node wind over the step window [tw0, tw1], s = (t - tw0)/(tw1 - tw0):  u(s) = u0 + s du + s (s - 1) bu  — the parabola through
+/* node wind over the step window [tw0, tw1], s = (t - tw0)/(tw1 - tw0):  u(s) = u0 + s (du + (s - 1) bu)  — the parabola through
  * the three levels u0 = u(tw0), um = u((tw0+tw1)/2), u1 = u(tw1) in Newton form, du = u1 - u0, bu = 2 ((u0 + u1) - 2 um).
  * Two-level winds (picles_set_winds, a lattice window without a knot) have bu = bv = 0 and are the straight line, bit for bit what
- * the two-level code computed: fma(0, g, fma(du, s, u0)) = fma(du, s, u0).  The reference calls the closures u(x,y,t), v(x,y,t) at every stage time
+ * the two-level code computed: fma(0, s - 1, du) = du.  The reference calls the closures u(x,y,t), v(x,y,t) at every stage time
  * (particle_waves_v5.jl:494-495); for a forcing of angular frequency ω the line misses it by (ω Δt)²/8 of its amplitude at
  * mid-step, the parabola by (ω Δt)³/125 (T04_2D_reg_test.jl:167 with Δt = 20 min: 3.2e-3 against 3.2e-5). */
 /* The other three-level form (P.wind_sk in (0,1)): a gridded wind is piecewise linear in t with kinks at the lattice's time knots, and
@@ -232,15 +232,24 @@ struct Wind {
     double u0, v0, du, dv; /* level 0 and (level1 - level0) [knot form: the first segment's slope per unit s] */
     double bu, bv;         /* curvature term of the three-level window (0: linear in t) [knot form: the slope's jump at the knot] */
 };
-/* both forms are  u(s) = u0 + s du + g(s) bu  with one shape function per window form, evaluated once per stage time for u and v:
- * g = s (s - 1) (parabola; two levels: bu = 0, the straight line) or g = max(s - sk, 0) (knot) */
-PM_HD double wind_shape(const KParams &P, double s)
+/* The parabola keeps the arithmetic of the two- and three-level windows of rounds 1-3, u0 + s (du + (s - 1) bu); the knot form sits
+ * behind ONE kernel-uniform (scalar) branch per evaluation that covers both components.  Measured on MI355X, default-solver flavour,
+ * same box (gpurun_out/r4c/ab_wind_form*.log): this shape costs the time-varying kernels 1.3 % over the code without a knot form;
+ * a common formula with a shape function g(s) selected per stage cost 8-12 % (the 168-register kernel sits at the edge of its
+ * allocation: one more live value across the stage evaluations moved spill code into the RK loop). */
+PM_HD void wind_eval2(const KParams &P, const Wind &w, double s, double &u, double &v)
 {
-    double sp = s - P.wind_sk;
-    sp = (sp > 0.0) ? sp : 0.0;
-    return (P.wind_sk > 0.0) ? sp : s * (s - 1.0);
+    if (P.wind_sk > 0.0) {
+        double sp = s - P.wind_sk;
+        sp = (sp > 0.0) ? sp : 0.0;
+        u = PM_FMA(w.bu, sp, PM_FMA(w.du, s, w.u0));
+        v = PM_FMA(w.bv, sp, PM_FMA(w.dv, s, w.v0));
+    } else {
+        const double s1 = s - 1.0;
+        u = PM_FMA(PM_FMA(w.bu, s1, w.du), s, w.u0);
+        v = PM_FMA(PM_FMA(w.bv, s1, w.dv), s, w.v0);
+    }
 }
-PM_HD double wind_eval(double u0, double du, double bu, double s, double g) { return PM_FMA(bu, g, PM_FMA(du, s, u0)); }
 /* d/ds of the same */
 PM_HD double wind_slope(const KParams &P, double du, double bu, double s)
 {
@@ -293,9 +302,7 @@ PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double 
         v = w.v0;
     } else {
         double s = (t - P.tw0) * P.inv_dtw;
-        double g = wind_shape(P, s);
-        u = wind_eval(w.u0, w.du, w.bu, s, g);
-        v = wind_eval(w.v0, w.dv, w.bv, s, g);
+        wind_eval2(P, w, s, u, v);
     }
 }
 template <bool STATIC>
@@ -303,8 +310,9 @@ PM_HD void wind_stage(const KParams &P, const Wind &w, double t, WindD &d)
 {
     if (!STATIC) {
         double s = (t - P.tw0) * P.inv_dtw;
-        double g = wind_shape(P, s);
-        wind_derive_stage(P, wind_eval(w.u0, w.du, w.bu, s, g), wind_eval(w.v0, w.dv, w.bv, s, g), d);
+        double u, v;
+        wind_eval2(P, w, s, u, v);
+        wind_derive_stage(P, u, v, d);
     }
 }
 

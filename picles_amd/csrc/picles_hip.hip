@@ -1727,6 +1727,9 @@ struct SlabRing {
     hipStream_t sE = nullptr, sM = nullptr;
     hipEvent_t evE = nullptr, evM = nullptr, evEd = nullptr;      /* evEd: this step's edge launch alone (without the exchange behind it) */
     unsigned long long steps = 0, exchanged_bytes = 0;
+    /* phase timing (picles_slab_get_phases): five events per step while per-launch timing is on */
+    struct PhaseEv { hipEvent_t e0, e1, x1, m0, m1; };
+    std::vector<PhaseEv> ph_used, ph_free;
 };
 
 #define NCCLCHK(c, R, call)                                                                     \
@@ -1763,6 +1766,8 @@ PX_EXPORT int32_t picles_slab_comm_destroy(picles_ctx *c)
     if (R->evE) hipEventDestroy(R->evE);
     if (R->evM) hipEventDestroy(R->evM);
     if (R->evEd) hipEventDestroy(R->evEd);
+    for (auto *v : {&R->ph_used, &R->ph_free})
+        for (auto &e : *v) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); hipEventDestroy(e.x1); hipEventDestroy(e.m0); hipEventDestroy(e.m1); }
     if (R->sE) hipStreamDestroy(R->sE);
     if (R->sM) hipStreamDestroy(R->sM);
     delete R;
@@ -1866,12 +1871,22 @@ PX_EXPORT int32_t picles_slab_run_steps(picles_ctx *c, double dt, int32_t n_step
         if (fused == 1) { int rc = picles_begin_step(c, dt, flags); if (rc) return rc; }
         /* the previous step's interior launch (stream M) wrote / read what the edge launch touches */
         HIPCHK(c, hipStreamWaitEvent(R->sE, R->evM, 0));
+        const bool phases = c->timing && c->timing_mode == 1 && R->ph_used.size() < (1u << 16);
+        SlabRing::PhaseEv pe{};
+        if (phases) {
+            if (!R->ph_free.empty()) { pe = R->ph_free.back(); R->ph_free.pop_back(); }
+            else { hipEventCreate(&pe.e0); hipEventCreate(&pe.e1); hipEventCreate(&pe.x1); hipEventCreate(&pe.m0); hipEventCreate(&pe.m1); }
+            HIPCHK(c, hipEventRecord(pe.e0, R->sE));
+        }
         int rc = (fused == 0) ? picles_step_rows(c, PICLES_ROWS_EDGE, R->sE) : picles_advance_rows(c, PICLES_ROWS_EDGE, R->sE);
         if (rc) return rc;
         if (fused == 0) HIPCHK(c, hipEventRecord(R->evEd, R->sE));
+        if (phases) HIPCHK(c, hipEventRecord(pe.e1, R->sE));
         if ((rc = ring_exchange(c, R, R->sE))) return rc;
+        if (phases) { HIPCHK(c, hipEventRecord(pe.x1, R->sE)); HIPCHK(c, hipEventRecord(pe.m0, R->sM)); }
         rc = (fused == 0) ? picles_step_rows(c, PICLES_ROWS_INTERIOR, R->sM) : picles_advance_rows(c, PICLES_ROWS_INTERIOR, R->sM);
         if (rc) return rc;
+        if (phases) { HIPCHK(c, hipEventRecord(pe.m1, R->sM)); R->ph_used.push_back(pe); }
         if (fused == 0) {
             /* fused steps: what runs next on M is the next step's interior launch.  Its pull reads own rows only — the records the
              * edge launch of THIS step wrote among them — never the ghost rows: it waits for the edge kernel, not for the exchange
@@ -1887,6 +1902,33 @@ PX_EXPORT int32_t picles_slab_run_steps(picles_ctx *c, double dt, int32_t n_step
         if (rc) return rc;
         R->steps++;
     }
+    return 0;
+}
+
+PX_EXPORT int32_t picles_slab_get_phases(picles_ctx *c, picles_slab_phases *out)
+{
+    if (!c || !out) return -1;
+    SlabRing *R = c->ring;
+    if (!R) return fail(c, -2, "picles_slab_comm_init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    picles_slab_phases P{};
+    for (auto &e : R->ph_used) {
+        float ed = 0.f, ex = 0.f, in = 0.f, sl = 0.f, se = 0.f, sm = 0.f;
+        hipEventElapsedTime(&ed, e.e0, e.e1);
+        hipEventElapsedTime(&ex, e.e1, e.x1);
+        hipEventElapsedTime(&in, e.m0, e.m1);
+        hipEventElapsedTime(&sl, e.x1, e.m1);      /* > 0: the interior launch ended after the exchange had completed */
+        hipEventElapsedTime(&se, e.e0, e.x1);
+        hipEventElapsedTime(&sm, e.e0, e.m1);
+        P.steps++;
+        if (sl >= 0.f) P.exchange_hidden++;
+        P.edge_ms += ed; P.exchange_ms += ex; P.interior_ms += in; P.slack_ms += sl;
+        P.span_ms += (se > sm) ? se : sm;
+        R->ph_free.push_back(e);
+    }
+    R->ph_used.clear();
+    *out = P;
     return 0;
 }
 

@@ -254,6 +254,17 @@ class HipModel:
         self._ck(self.lib.picles_slab_streams(self.h, C.byref(e), C.byref(m)), "picles_slab_streams")
         return e.value, m.value
 
+    def slab_phases(self):
+        """where the ring steps' time went since the last call (picles_slab_get_phases; needs enable_timing(1)): per-step means
+        [ms] of the edge launch, the exchange behind it and the interior launch, and how often the exchange was hidden"""
+        p = K.PiclesSlabPhases()
+        self._ck(self.lib.picles_slab_get_phases(self.h, C.byref(p)), "picles_slab_get_phases")
+        d = p.as_dict()
+        n = max(d["steps"], 1)
+        return {"steps": d["steps"], "exchange_hidden_steps": d["exchange_hidden"], "edge_ms": d["edge_ms"] / n,
+                "exchange_ms": d["exchange_ms"] / n, "interior_ms": d["interior_ms"] / n, "slack_ms": d["slack_ms"] / n,
+                "span_ms": d["span_ms"] / n}
+
     def slab_comm_destroy(self):
         self._ck(self.lib.picles_slab_comm_destroy(self.h), "picles_slab_comm_destroy")
 

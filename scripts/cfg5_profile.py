@@ -1,5 +1,5 @@
 """BASELINE config 5 (2048², growing / decaying winds with the time factor cos(3t/(3600·2π)), 20-minute steps, default solver) with the
-forcing as a device lattice: per-launch kernel times, RHS throughput, the lane efficiency of the adaptive advance (device counters:
+forcing as a device lattice in SMOOTH3 mode (three device-sampled levels per step: the conformant path): per-launch kernel times, RHS throughput, the lane efficiency of the adaptive advance (device counters:
 Σ lane RK attempts ÷ Σ 64 × wave maximum) and, for scale, the homogeneous box of the same size and solver.  One JSON line per run.
     python scripts/cfg5_profile.py [steps]        (under rocprofv3 for profiles/r3_cfg5_*)"""
 import json
@@ -42,13 +42,8 @@ def run(name, cfg, warm, steps):
     return out
 
 
-cfg = configs.growing_decaying_winds(n=2048)
-g = cfg.model["grid"]
-x = g.data.x[:, 0]; y = np.array([0.0, g.data.y[0, -1]]); t = np.arange(0.0, (STEPS + 6) * cfg.Δt, cfg.Δt)
-X, Y, T = np.meshgrid(x, y, t, indexing="ij")
-w = wind_interpolator(dict(x=x, y=y, t=t, u=cfg.model["winds"].u(X, Y, T), v=cfg.model["winds"].v(X, Y, T)))
-cfg.model["winds"] = w; cfg.model["ODEsys"].u, cfg.model["ODEsys"].v = w.u, w.v
-a = run("cfg5 2048x2048 growing/decaying winds, device lattice, AutoTsit5", cfg, 2, STEPS)
+cfg = configs.growing_decaying_winds_lattice(n=2048, n_steps=STEPS + 4)      # SMOOTH3: three device-sampled levels per step, knots at Δt/2
+a = run("cfg5 2048x2048 growing/decaying winds, device lattice SMOOTH3 (conformant: three levels per step), AutoTsit5", cfg, 2, STEPS)
 box = configs.box4096(n=2048)
 box.model["ODEsets"].solver = "AutoTsit5"
 b = run("homogeneous periodic 2048x2048 box, winds (10,10), AutoTsit5 (bench06 physics)", box, 5, 20)

@@ -29,7 +29,7 @@ def _check(d, need_cpu):
         assert c["value"] > 0 and c["cores"] >= 1
 
 
-@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json"])
+@pytest.mark.parametrize("name", ["r1_bench.json", "r2_bench.json", "r3_bench.json"] + (["r4_bench.json"] if (ROOT / "profiles" / "r4_bench.json").exists() else []))
 def test_committed_profile_line(name):
     lines = [l for l in (ROOT / "profiles" / name).read_text().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -39,6 +39,10 @@ def test_committed_profile_line(name):
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 64 * d["config"]["particles"]
     if name.startswith("r2"):
         _check_round2_fields(d, r3=False)
+    if name.startswith(("r3", "r4")):
+        _check_round2_fields(d, r3=True)
+    if name.startswith("r4"):
+        _check_round4_legs(d)
 
 
 def _check_round2_fields(d, steady=True, r3=True):
@@ -57,6 +61,20 @@ def _check_round2_fields(d, steady=True, r3=True):
     for s in sec.values():
         assert s["ms_per_step"] > 0 and s["rhs_evals_per_particle_step"] > 20 and 0 < s["fp64_frac"] < 1 and s["halo_overflow"] == 0
     assert sec[((10.0, 3.0), "DP5")]["rhs_evals_per_particle_step"] > 5 * d["fp64"]["rhs_evals_per_particle_step"]
+
+
+def _check_round4_legs(d):
+    """round 4: what the rounds optimise rides in the driver-timed line — BASELINE config 5 on its conformant device
+    path, the developed sea (scatter reach 2), one rank's slab of the 8-GPU run, plain and as a ring of one"""
+    legs = d["secondary_legs"]
+    assert set(legs) == {"cfg5_conformant_device_lattice", "box_reach2", "slab_4096x512", "slab_4096x512_ring_of_one"}
+    for k, v in legs.items():
+        assert "error" not in v, (k, v)
+        assert v["ms_per_step"] > 0 and v["halo_overflow"] == 0
+    c5 = legs["cfg5_conformant_device_lattice"]
+    assert "SMOOTH3" in c5["workload"] and 0 < c5["lane_efficiency"] <= 1 and c5["max_reach"] >= 2 and 0 < c5["rhs_rate_over_homogeneous_box"] < 1.5
+    assert legs["box_reach2"]["max_reach"] == 2
+    assert legs["slab_4096x512_ring_of_one"]["slab_phases"]["steps"] == d["steps"]
 
 
 @pytest.mark.gpu
@@ -114,19 +132,23 @@ def shm_ccl(tmp_path_factory):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 4])
-def test_multi_process_launch_path_end_to_end_on_one_gpu(shm_ccl, world):
+@pytest.mark.parametrize("world,n", [(2, 512), (4, 4096)])
+def test_multi_process_launch_path_end_to_end_on_one_gpu(shm_ccl, world, n):
     """what the driver's SCALE run executes — `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`:
     N processes, rendezvous, the communicator id handed out by a torch.distributed broadcast, every rank in the library's NATIVE
     ring (picles_slab_comm_init / picles_slab_run_steps), the reductions of the result line, the state check across the slabs,
     one JSON line from rank 0 — with every rank on the ONE GPU of the test box.  RCCL refuses two ranks per device, so the
     library binds a multi-process shared-memory communicator instead (PICLES_CCL_LIB = tests/native/shm_ccl.cpp) and
-    torch.distributed runs on gloo; everything else is the code path of the real run."""
+    torch.distributed runs on gloo; everything else is the code path of the real run.
+    Round 4: four ranks at the real width (--grid-n 4096: the halo message and the row length of the 8-GPU run; 1024-row slabs).  The
+    eight PROCESSES of the real run cannot share one card here — the GPU boxes allow at most six processes on it — so the 8 x 512
+    shape runs as eight thread-ranks over the loopback communicator (tests/test_gpu_loopback_ring.py).  The result line must carry
+    the per-rank phase diagnosis (`slab_phases`) the first hardware run will be read by."""
     from helpers import free_port
     env = dict(os.environ, PICLES_CCL_LIB=str(shm_ccl), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
-           "--grid-n", "512", "--backend", "gloo", "--native-ring", "--no-cpu"]
+           "--grid-n", str(n), "--backend", "gloo", "--native-ring", "--no-cpu"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=540)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -135,5 +157,11 @@ def test_multi_process_launch_path_end_to_end_on_one_gpu(shm_ccl, world):
     _check(d, need_cpu=False)
     assert d["n_gpus"] == world and d["steps"] == 4 and d["scaling"] == "strong"
     assert "picles_slab_run_steps" in d["config"]["step_loop"]
-    assert d["state_check"]["rel_spread"] < 1e-9 and d["config"]["particles"] == 512 * 512
+    assert d["state_check"]["rel_spread"] < 1e-9 and d["config"]["particles"] == n * n
     assert d["roofline"]["launches"] == 8            # rank 0's edge + interior launch per step
+    assert "(1 row)" in d["config"]["parallelism"]   # --halo defaults to what the 2 + 4 steps need
+    ph = d["slab_phases"]["per_rank"]
+    assert sorted(p["rank"] for p in ph) == list(range(world))
+    for p in ph:
+        assert p["steps"] == 4 and p["edge_ms"] > 0 and p["interior_ms"] > 0 and p["exchange_ms"] >= 0 and 0 <= p["exchange_hidden_steps"] <= 4
+        assert p["step_span_ms"] >= max(p["edge_ms"], p["interior_ms"]) * 0.99

@@ -35,6 +35,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(K.PiclesOde) == 4 * 8 + 2 * 4 + 8 + 4 * 8
     assert C.sizeof(K.PiclesModel) == 8 + 5 * 8
     assert C.sizeof(K.PiclesCounters) == 8 * 8 + 8 + 8 + 8
+    assert C.sizeof(K.PiclesSlabPhases) == 2 * 8 + 5 * 8
 
 
 def _header_structs():
@@ -172,7 +173,7 @@ def test_ctypes_binding_matches_header_prototypes():
         return {C.c_int32: "i32", C.c_int64: "i64", C.c_double: "f64", C.c_uint8: "u8", C.c_int8: "i8", C.c_size_t: "u64",
                 C.c_uint64: "u64"}.get(t, getattr(t, "__name__", str(t)))
     structs = {"PiclesGrid": "picles_grid", "PiclesPhys": "picles_phys", "PiclesOde": "picles_ode", "PiclesModel": "picles_model",
-               "PiclesCounters": "picles_counters", "PiclesTiming": "picles_timing"}
+               "PiclesCounters": "picles_counters", "PiclesTiming": "picles_timing", "PiclesSlabPhases": "picles_slab_phases"}
     for name, (res, args) in K.SYMBOLS.items():
         cret, cargs = protos[name]
         assert norm_ct(res) == _norm_c(cret), (name, res, cret)
