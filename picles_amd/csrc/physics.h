@@ -463,7 +463,18 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
     double Sd = 0.0;
     if (FAST || P.direction) {
         /* S_dir = C_φ α² H sin 2(θ_c - θ_w) = [2 C_φ/(r_g² U²)]·(c̄ × u)(c̄ · u)·(1/c_gp²)·α² H; 0 for a vanishing wind or c̄ */
-        if (!(W.U2 == 0.0 || c2 == 0.0)) Sd = ((crsc * dotc) * (rc2 * aH)) * W.sK;
+        /* (the guard behind a wave-uniform test: a compare and a scalar branch where every lane has a wind and a c̄ — the normal
+         * case — instead of a compare and two selects; same bits either way) */
+        /* (the guard behind a wave-uniform test on the product — zero when either factor is, or when both are below 1e-162: the rare
+         * path repeats the exact test — one multiplication, one compare and a scalar branch where every lane has a wind and a c̄
+         * instead of two compares and two selects; same bits either way) */
+        const double Sd_ = ((crsc * dotc) * (rc2 * aH)) * W.sK;
+        if (PM_WAVE_ALL(!(W.U2 * c2 == 0.0))) {
+            Sd = Sd_;
+        } else {
+            PM_RARE_PATH();
+            if (!(W.U2 == 0.0 || c2 == 0.0)) Sd = Sd_;
+        }
         /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned.  Only the general-physics
          * kernels carry it (a run-time test here costs the specialised kernel 2.6 %, measured; a compile-time flavour of it
          * doubled the kernel count): a context with a dead band runs the general kernels */

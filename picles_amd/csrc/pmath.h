@@ -81,6 +81,22 @@ PM_HD double pm_fmax_c(double a, double c) { return __builtin_fmax(a, c); }
 PM_HD double pm_fmax_abs(double a, double b) { return __builtin_fmax(__builtin_fabs(a), __builtin_fabs(b)); }
 #endif
 
+/* A constant pinned to a scalar register pair AT ITS USE.  The compiler's habit with fp64 literals that are neither inline
+ * constants nor "high dword only" is to park them in VGPR pairs for the whole kernel (loop-invariant) and, for a Horner step
+ * p = fma(p, z, C), to copy C into the accumulator first (v_mov_b64 + v_fmac: two issue slots).  Inside the Runge-Kutta loop of the
+ * fused step that was 14 vector registers of constants at a 128-register budget.  With the addend in scalar registers the step is one
+ * v_fma_f64 (one scalar operand per instruction is allowed), the two s_mov that rebuild the pair each time go to the scalar unit,
+ * which has slack.  (volatile: not hoisted out of the loop into the — full — scalar file.)  Identity on the host. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double pm_sc(double c)
+{
+    __asm__ volatile("" : "+s"(c));
+    return c;
+}
+#else
+PM_HD double pm_sc(double c) { return c; }
+#endif
+
 /* 2^k for -1022 <= k <= 1023 */
 PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
 
@@ -167,10 +183,14 @@ __device__ __forceinline__ void pm_device_init(void) {}   /* host pass of hipcc:
  * r^5/120 <= 1.2e-18 is far below the rounding of the final product. */
 PM_HD double pm_exp_core(double x)
 {
-    double k = __builtin_rint(x * PM_EXP_RN);
+    /* k = rint(x 512/ln2) through the shifter 1.5·2^52: the sum is rounded to an integer by the addition itself (round to nearest
+     * even, |x 512/ln2| < 2^20), its low 32 mantissa bits ARE k in two's complement, and the subtraction that recovers k as a
+     * double is exact — two issue slots (fma, add) instead of three (mul, rndne, cvt) */
+    const double kd = PM_FMA(x, PM_EXP_RN, 6755399441055744.0);
+    const double k = kd - 6755399441055744.0;
     double r = PM_FMA(-k, PM_EXP_LHI, x);
     r = PM_FMA(-k, PM_EXP_LLO, r);
-    int ki = (int)k;
+    int ki = (int)(uint32_t)pm_bits(kd);
     int j = ki & (PM_EXP_N - 1);
     int m = ki >> PM_EXP_SHIFT;
     double p = 4.1666666666666664e-02;                /* 1/4! */
@@ -288,8 +308,8 @@ PM_HD double pm_log_coarse(double x)
     double f = m - 1.0;
     double s = pm_div_plain(f, 2.0 + f);      /* 2 + f in [1.70, 2.42] */
     double z = s * s;
-    double p = PM_FMA(z, PM_FMA(z, PM_FMA(z, PM_FMA(z, 2.0 / 9.0, 2.0 / 7.0), 2.0 / 5.0), 2.0 / 3.0), 2.0);
-    return PM_FMA((double)k, 6.93147180559945286227e-01, s * p);
+    double p = PM_FMA(z, PM_FMA(z, PM_FMA(z, z * pm_sc(2.0 / 9.0) + pm_sc(2.0 / 7.0), pm_sc(2.0 / 5.0)), pm_sc(2.0 / 3.0)), 2.0);
+    return PM_FMA((double)k, pm_sc(6.93147180559945286227e-01), s * p);
 }
 
 PM_HD double pm_pow(double x, double y) { return pm_exp(y * pm_log(x)); }

@@ -138,8 +138,9 @@ def test_stand_alone_advance_reloads_its_arguments_in_every_flavour():
         if not name.startswith("_Z9k_advance"):
             continue
         general_auto = name.startswith("_Z9k_advanceILb0E") and name.split("EEv")[0].endswith("ELb1")
-        # (24, not 20: the general-physics time-varying flavours keep the knot position of a gridded wind's window since round 4: 22)
-        assert u["sspill"] <= (110 if general_auto else 24), (name, u)
+        # (28, not 20: the time-varying flavours keep the knot position of a gridded wind's window since round 4, and the polynomial
+        # constants pinned to scalar registers at their use (pmath.h, pm_sc) trade vector for scalar pressure: 22 - 26)
+        assert u["sspill"] <= (110 if general_auto else 28), (name, u)
         assert u["scratch"] <= 96, (name, u)
 
 
