@@ -1,14 +1,8 @@
 /* k_advance.hip — the stand-alone advance kernel and its instantiations */
-#ifndef PICLES_TABLEAU_SMEM
-#define PICLES_TABLEAU_SMEM(FAST, AUTO) ((FAST) && !(AUTO))      /* Butcher tableau through scalar loads in the four-wave flavours (physics.h) */
-#endif
 /* every flavour parks (particle index, node, flags) in LDS and reads its arguments again behind the RK loop instead of keeping
  * them in scalar registers across it (k_step.inc has the reasons): scalar spills 61-105 -> 12-18 in the general-physics and
- * auto-switching flavours (the general-physics auto-switching pair keeps ~100: its Jacobian reads most of KParams) */
-#ifndef PICLES_ADV_RELOAD
-#define PICLES_ADV_RELOAD(FAST, AUTO) true
-#endif
-#define PICLES_ROS_KARGS 1                          /* the Rosenbrock23 branch re-reads KParams from the kernarg segment (physics.h) */
+ * auto-switching flavours (the general-physics auto-switching pair keeps ~100: its Jacobian reads most of KParams).  The Butcher
+ * tableau goes through scalar loads in the four-wave flavours (FAST && !AUTO), through LDS in the others (physics.h, TABS). */
 #include "kernels.h"
 
 /* the kernel arguments as the kernarg segment lays them out (kargs_reload, kernels.h: behind the RK loop they are read again
@@ -65,15 +59,16 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
             write_record(Gq, Aq, iq, jlq, pfq, on, z, S);
             rtile = (int)(tq >> 6);
         };
-        if constexpr (PICLES_ADV_RELOAD(FAST, AUTO)) {
+        {
             /* what is needed again only behind the loop waits in LDS, and the kernel arguments are read
              * again from the kernarg segment (k_step.inc has the reasons) */
+            constexpr bool TABS = FAST && !AUTO;
             __shared__ int stash_[5][256];
             const int tid_ = threadIdx.x;
             stash_[0][tid_] = (int)(unsigned int)((unsigned long long)t & 0xffffffffull); stash_[1][tid_] = (int)((unsigned long long)t >> 32);
             stash_[2][tid_] = i; stash_[3][tid_] = jl; stash_[4][tid_] = (int)pf;
-            if (METRIC) status = advance_core<FAST, STATIC, true, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
-            else status = advance_core<FAST, STATIC, false, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
+            if (METRIC) status = advance_core<FAST, STATIC, true, TSIT, AUTO, TABS>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
+            else status = advance_core<FAST, STATIC, false, TSIT, AUTO, TABS>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
             const KAdvArgs *K = (const KAdvArgs *)kargs_reload();
             const KParams Pb = K->P;
             const GridP Gb = K->G;
@@ -82,10 +77,6 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
             const int tid2_ = threadIdx.x;
             const long long tb = (long long)(((unsigned long long)(unsigned int)stash_[1][tid2_] << 32) | (unsigned int)stash_[0][tid2_]);
             finish(Pb, Gb, Ab, tb, stash_[2][tid2_], stash_[3][tid2_], (unsigned char)(stash_[4][tid2_] & 0xff), K->t_start, K->DT, status);
-        } else {
-            if (METRIC) status = advance_core<FAST, STATIC, true, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, A.m11[t], A.m22[t], A.pc[t], &asw);
-            else status = advance_core<FAST, STATIC, false, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, 0.0, 0.0, 0.0, &asw);
-            finish(P, G, A, t, i, jl, pf, t_start, DT, status);
         }
     }
     flush_stats(A, S, rtile);

@@ -1,7 +1,4 @@
 /* k_step_auto.hip — instantiations of the fused step kernel for AutoTsit5(Rosenbrock23()), specialised physics */
-#define PICLES_TABLEAU_SMEM(FAST, AUTO) true      /* Butcher tableau through scalar loads (physics.h): 100 -> 60 B/lane of scratch at three waves */
-#define PICLES_PREFETCH 1                           /* flags, wind, controller memory are loaded ahead of the pull (k_step.inc): -1 % at three waves per SIMD, +4 % at four */
-#define PICLES_ROS_KARGS 1                          /* the Rosenbrock23 branch re-reads KParams from the kernarg segment (physics.h) */
 #include "kernels.h"
 #include "k_step.inc"
 

@@ -1,5 +1,4 @@
 /* k_step_explicit.hip — instantiations of the fused step kernel for the explicit 5(4) pairs (DP5, Tsit5) */
-#define PICLES_TABLEAU_SMEM(FAST, AUTO) true      /* Butcher tableau through scalar loads (physics.h): what makes four waves per SIMD fit */
 #include "kernels.h"
 #include "k_step.inc"
 

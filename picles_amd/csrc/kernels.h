@@ -1,6 +1,6 @@
 /*
  * kernels.h — device-side code shared by the translation units of libpicles_hip.so: the kernel argument structs (GridP, Arrays),
- * the per-particle step (advance_particle, write_record, flush_stats), NodeToParticle! in registers and the deterministic pull
+ * the per-particle step (advance_core, advance_guards, write_record, flush_stats), NodeToParticle! in registers and the deterministic pull
  * scatter.  Everything here is __device__ __forceinline__ or a plain struct; the kernels themselves live in
  *   picles_hip.hip      k_seed, k_scatter, k_remesh, k_push_tiles, the cell list, k_wind_sample + the host side / C ABI
  *   k_step_explicit.hip  the fused step, DP5 and Tsit5 flavours          k_step_auto.hip   ... AutoTsit5(Rosenbrock23())
@@ -171,7 +171,7 @@ struct StepStats {
 
 /* advance! in two halves: the step itself (on: the whole adaptive integration; off: the wind test) and the guards behind it.
  * k_step re-reads its kernel arguments between the two (kargs_reload below). */
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false, bool TABS = true>
 __device__ __forceinline__ int advance_core(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
                                             double &dtn, double t_start, double DT, StepStats &S,
                                             double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
@@ -179,7 +179,7 @@ __device__ __forceinline__ int advance_core(const KParams &P, const Wind &w, Vec
     int status = PICLES_ST_STEPPED;
     if (on) {
         S.adv = 1;
-        integrate_dp5<FAST, STATIC, METRIC, TSIT, AUTO>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc, asw);
+        integrate_dp5<FAST, STATIC, METRIC, TSIT, AUTO, TABS>(P, w, z, qold, dtn, t_start, DT, S.st, m11, m22, pc, asw);
         status |= S.st.status;
     } else {
         double u, v;
@@ -223,15 +223,6 @@ __device__ __forceinline__ int advance_guards(const KParams &P, WF wind, Vec5 &z
     if (status & PICLES_ST_CLAMPED) S.clamps = 1;
     if (status & PICLES_ST_MAXITERS) S.maxit = 1;
     return status;
-}
-
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
-__device__ __forceinline__ int advance_particle(const KParams &P, const Wind &w, Vec5 &z, int &on, double &qold,
-                                                double &dtn, double t_start, double DT, StepStats &S,
-                                                double m11 = 0.0, double m22 = 0.0, double pc = 0.0, int *asw = nullptr)
-{
-    int status = advance_core<FAST, STATIC, METRIC, TSIT, AUTO>(P, w, z, on, qold, dtn, t_start, DT, S, m11, m22, pc, asw);
-    return advance_guards(P, [&]() { return w; }, z, dtn, t_start, DT, status, S);
 }
 
 /* The kernel arguments of k_step as the kernarg segment lays them out (same order, natural alignment = the C struct rule;

@@ -186,23 +186,21 @@ PM_HD void dp_load(DPTab &T, int solver)
  * wave-uniform address: the LDS port is otherwise idle, and the 26 live constants would cost 52 VGPRs); the fused step kernels
  * (k_step_explicit.hip, k_step_auto.hip): scalar loads (below); on the host a plain struct */
 #if defined(__HIP_DEVICE_COMPILE__)
-/* PICLES_TABLEAU_SMEM(FAST, AUTO): which instantiations of a translation unit take the scalar-load form (default: none).
+/* TABS (template parameter of integrate_dp5 / advance_core): the instantiation takes the scalar-load form.
  * Scalar-load form: every use is a SCALAR load from constant memory, issued stage by stage behind an opaque copy of the table
  * pointer (TT_STAGE: the loads of a stage cannot be hoisted above it, so at most one stage's coefficients are live: ~16 SGPRs), and
  * enters the fma as its scalar operand.  No VGPR ever holds a coefficient — with the LDS form the constants in flight cost ~30
  * VGPRs — which is what lets the DP5 / Tsit5 kernels fit 128 registers = FOUR waves per SIMD (2.40 -> 2.28 ms on the BASELINE box,
- * same instruction count).  As literals (s_mov at the point of use) the same constants overflowed the scalar file: 44 spilled
- * SGPRs, +40 VALU slots per attempt, +5 %.  Every barrier starts from the table's address again, not from the previous copy: no
- * value is carried across the (divergent) branches of the auto-switching kernel, whose merge would otherwise turn the pointer into
- * a per-lane value.  The form needs scalar registers to spare: the general-physics and auto-switching flavours of the stand-alone
- * advance kernel, which keep all their arguments live, stay with LDS. */
-#ifndef PICLES_TABLEAU_SMEM
-#define PICLES_TABLEAU_SMEM(FAST, AUTO) false
-#endif
+ * same instruction count; the default-solver step kernels: 100 -> 60 B/lane of scratch at three waves).  As literals (s_mov at the
+ * point of use) the same constants overflowed the scalar file: 44 spilled SGPRs, +40 VALU slots per attempt, +5 %.  Every barrier
+ * starts from the table's address again, not from the previous copy: no value is carried across the (divergent) branches of the
+ * auto-switching kernel, whose merge would otherwise turn the pointer into a per-lane value.  The form needs scalar registers to
+ * spare: every fused step kernel takes it; of the stand-alone advance kernels only the four-wave flavours (specialised physics,
+ * explicit pair) — the general-physics and auto-switching ones keep all their arguments live and stay with LDS. */
 typedef const __attribute__((opencl_constant)) double *dp_cptr;
 __device__ __forceinline__ dp_cptr dp_launder(dp_cptr p) { __asm__ volatile("" : "+s"(p)); return p; }
 #define DP_TAB_DECL(solver)                                                                                      \
-    constexpr int dp_solver_ = (solver); constexpr bool dp_smem_ = PICLES_TABLEAU_SMEM(FAST, AUTO);              \
+    constexpr int dp_solver_ = (solver); constexpr bool dp_smem_ = TABS;                                          \
     dp_cptr dp_ctab_ = (dp_cptr)&DPTAB_C[dp_solver_][0]; const double *const dp_ltab_ = dp_lds_tab()
 #define TT_STAGE() do { if constexpr (dp_smem_) dp_ctab_ = dp_launder((dp_cptr)&DPTAB_C[dp_solver_][0]); } while (0)
 #define TT(f) (dp_smem_ ? dp_ctab_[__builtin_offsetof(DPTab, f) / 8] : dp_ltab_[__builtin_offsetof(DPTab, f) / 8])
@@ -613,15 +611,12 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     }
 }
 
-/* The Rosenbrock23 attempt reads its parameters afresh from the kernarg segment (PICLES_ROS_KARGS: translation units whose kernels
- * take KParams as their FIRST argument — k_step, k_advance).  The branch is entered by a minority of attempts, but what it alone
- * needs — C_φ, 2/r_g², 1/e_T⁴, C_α, the unfolded constants of the Jacobian — would otherwise sit in scalar registers through all
- * seven Tsit5 stages of every attempt; the scalar file overflows there and its spill code (v_readlane / v_writelane) is VALU work
- * inside the loop.  Behind an opaque copy of the segment pointer the loads stay inside the branch (scalar loads, K$ hits). */
-#ifndef PICLES_ROS_KARGS
-#define PICLES_ROS_KARGS 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && PICLES_ROS_KARGS
+/* The Rosenbrock23 attempt reads its parameters afresh from the kernarg segment (every kernel that reaches it — k_step, k_advance —
+ * takes KParams as its FIRST argument).  The branch is entered by a minority of attempts, but what it alone needs — C_φ, 2/r_g²,
+ * 1/e_T⁴, C_α, the unfolded constants of the Jacobian — would otherwise sit in scalar registers through all seven Tsit5 stages of
+ * every attempt; the scalar file overflows there and its spill code (v_readlane / v_writelane) is VALU work inside the loop.
+ * Behind an opaque copy of the segment pointer the loads stay inside the branch (scalar loads, K$ hits). */
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ const KParams &ros_params(const KParams &)
 {
     auto p = __builtin_amdgcn_kernarg_segment_ptr();
@@ -809,7 +804,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
 /* AUTO (solver 2, implies TSIT): AutoTsit5(Rosenbrock23()) — after every attempt the AutoSwitch tests
  * |eigen_est·dt_next/3.5068| > 0.9; more than 10 successive positives hand over to Rosenbrock23 (dt·2), more than 3
  * successive negatives hand back (dt/2).  *asw carries (counter << 1 | rosenbrock_active) across model steps. */
-template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false>
+template <bool FAST, bool STATIC, bool METRIC = false, bool TSIT = false, bool AUTO = false, bool TABS = true>
 PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, double &dtn,
                          double t_start, double DT, PStats &st, double m11 = 0.0, double m22 = 0.0, double pc = 0.0,
                          int *asw = nullptr)
