@@ -82,6 +82,25 @@ def budget(unit, prefix, verbose=False):
         if cur is None or not t or t.startswith((";", ".", "//")):
             continue
         cur["ins"].append(t.split(";")[0].strip())
+    # instructions that the stream skips with a wave-uniform branch placed right before them (s_cbranch_scc* to the NEXT label: the
+    # form PM_WAVE_ALL / PM_RARE_PATH compile to) are a rare path: split off into a block of their own, listed, and left out of the
+    # common-path totals
+    split = []
+    for k, b in enumerate(blocks):
+        nxt_label = blocks[k + 1]["label"] if k + 1 < len(blocks) else None
+        cut = None
+        for q, ins in enumerate(b["ins"]):
+            mm = re.match(r"s_cbranch_scc[01]\s+\.(LBB\d+_\d+)", ins)
+            if mm and mm.group(1) == nxt_label and q + 1 < len(b["ins"]):
+                cut = q + 1
+                break
+        b["rare"] = False
+        if cut is None:
+            split.append(b)
+        else:
+            split.append({"label": b["label"], "hdr": b["hdr"], "ins": b["ins"][:cut], "rare": False})
+            split.append({"label": b["label"] + "+", "hdr": b["hdr"], "ins": b["ins"][cut:], "rare": True})
+    blocks = split
     prod = Counter()
     for b in blocks:
         if b["hdr"]:
@@ -92,8 +111,9 @@ def budget(unit, prefix, verbose=False):
     for b in blocks:
         if b["hdr"] and b["hdr"][0] == rk:
             c = Counter(classify(i) for i in b["ins"])
-            per_block.append((b["label"], sum(c.values()), c))
-            tot.update(c)
+            per_block.append((b["label"] + (" (rare)" if b["rare"] else ""), sum(c.values()), c))
+            if not b["rare"]:
+                tot.update(c)
     return m.group(1), rk, tot, per_block
 
 
@@ -101,7 +121,7 @@ def main():
     unit, prefix = sys.argv[1], sys.argv[2]
     name, rk, tot, per_block = budget(unit, prefix)
     valu = sum(v for k, v in tot.items() if k.split(" ")[0] in ("fp64", "cvt", "mov", "select", "lane", "int") or k.startswith("other:v_"))
-    print(f"{name}\nRK loop header {rk}: {sum(tot.values())} instructions in {len(per_block)} blocks, {valu} VALU")
+    print(f"{name}\nRK loop header {rk}, common path (blocks behind a wave-uniform skip left out): {sum(tot.values())} instructions, {valu} VALU")
     for k in list(CLASSES) + sorted(x for x in tot if x.startswith("other:")):
         if tot.get(k):
             print(f"  {k:72s} {tot[k]:5d}")
