@@ -107,7 +107,7 @@ def measured_traffic(args, world):
     the profile was taken on this exact workload AND on this exact kernel (the profile carries a hash of the
     kernel's sources: an edited kernel reports null until the PMC passes are collected again); PMC counters
     cannot be read live in a timed run."""
-    f = next((q for q in (ROOT / "profiles" / "r3_pmc_traffic.json",) if q.exists()), None)
+    f = next((q for q in (ROOT / "profiles" / "r4_pmc_traffic.json", ROOT / "profiles" / "r3_pmc_traffic.json") if q.exists()), None)
     try:
         d = json.loads(f.read_text())
         if (world == 1 and d["config"]["n"] == args.n and tuple(d["config"]["winds"]) == tuple(args.winds)
@@ -369,7 +369,7 @@ def main():
                 "achieved_tflops": tflops,
                 "peak_tflops": FP64_PEAK_TFLOPS * world,
                 "frac": tflops / (FP64_PEAK_TFLOPS * world),
-                # from the committed PMC profile of this exact workload (profiles/r3_pmc_traffic.json, quoted only while its kernel stamp matches the tree), null otherwise
+                # from the committed PMC profile of this exact workload (profiles/r4_pmc_traffic.json, quoted only while its kernel stamp matches the tree), null otherwise
                 "valu_issue_busy": valu_busy,
                 "valu_insts_per_wave": valu_per_wave,
             },

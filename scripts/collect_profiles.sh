@@ -4,7 +4,7 @@
 # then, back in the build container:  python scripts/make_profiles.py r2
 # Each rocprofv3 pass is its own process; the --pmc passes carry no trace domains.
 set -o pipefail
-R=${1:-r3}
+R=${1:-r4}
 O=gpurun_out
 rm -rf $O/${R}_stats $O/${R}_stats_generic $O/${R}_stats_ring $O/${R}_pmc_sq $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_sq_auto $O/${R}_pmc_sq_auto_generic $O/${R}_cfg5_stats $O/${R}_cfg5_pmc_sq $O/${R}_cfg5_pmc_fetch $O/${R}_cfg5_pmc_write
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 """collect the rocprofv3 outputs of the round's measurement run (gpurun_out/r1_*) into profiles/"""
 import csv, glob, collections, json, shutil, sys
 from pathlib import Path
-R = sys.argv[1] if len(sys.argv) > 1 else "r3"
+R = sys.argv[1] if len(sys.argv) > 1 else "r4"
 root = Path(__file__).resolve().parent.parent
 out = root / "profiles"; out.mkdir(exist_ok=True)
 G = root / "gpurun_out"
