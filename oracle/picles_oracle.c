@@ -37,6 +37,13 @@
 #ifdef PO_PMATH
 #include "../picles_amd/csrc/pmath.h"
 #define o_exp pm_exp
+/* the kernels' saturating exponential of the energy, exp(min(max(x, -700), 700)) (pmath.h pm_exp_sat) */
+static inline double o_exp_sat(double x)
+{
+    x = (x > 700.0) ? 700.0 : x;
+    x = (x < -700.0) ? -700.0 : x;
+    return pm_exp(x);
+}
 #define o_log pm_log
 #define o_log_coarse pm_log_coarse
 #define o_rsqrt pm_rsqrt
@@ -48,6 +55,7 @@ static inline double o_exp10(double x) { return pm_exp(x * 2.3025850929940456840
 #define PO_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #else
 #define o_exp exp
+#define o_exp_sat exp
 #define o_log log
 #define o_log_coarse log
 static inline double o_rsqrt(double x) { return 1.0 / sqrt(x); }
@@ -310,48 +318,67 @@ static void po_rhs_literal(const po_model *M, int64_t idx, const double z[5], do
     }
 }
 
-/* KERNEL order: the same RHS as the HIP kernels evaluate it (DESIGN.md "Kernel order").
- * One reciprocal 1/c_gp feeds k_p, ω_p, α, α_p and sin2; |g| is taken as c_gp (identical in
- * exact arithmetic); sin 2(θ_c-θ_w) is evaluated as 2·cross·dot/(U|g|)² (algebraically equal to
- * sin2_a_min_b :242-249, exactly zero for aligned vectors); H_β via the logistic function,
- * sech² via one exp; fused multiply-adds written out. */
+/* KERNEL order: the same RHS as the HIP kernels evaluate it (DESIGN.md "Kernel order", physics.h rhs3).
+ * Everything is expressed through y = 1/|c̄| (1/c_gp = r_g y; one deterministic reciprocal square root feeds k_p, ω_p, α, α_p and
+ * sin2, the powers of r_g ride in the constants); |g| is taken as c_gp (identical in exact arithmetic); sin 2(θ_c-θ_w) is
+ * evaluated as 2·cross·dot/(U|g|)² (algebraically equal to sin2_a_min_b :242-249, exactly zero for aligned vectors); H_β and the
+ * sech² of Δ_β from one exponential and one reciprocal; fused multiply-adds written out.
+ * The reference's guards — max(c_gp, 0.1) in ω_p and k_p (:331-336), max(c_gp, 1e-4) in α_p (:505-507), min(α, 500) (:340), the
+ * zero tests of sin2_a_min_b — are ceilings ymax, sgmax on y, y², a cap on α² and the same zero tests; for a PLAIN particle
+ * (y <= ymax under a wind with 1e-290 <= U² and (U²/4) r_g² <= qU2r_max) none of them acts, the wind speed cancels out of the
+ * direction term, and the kernels evaluate the shorter form below; every other particle takes the guarded form. */
 static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], double u, double v, double dz[5])
 {
     const picles_phys *ph = &M->ph;
     const po_consts *k = &M->k;
     double lne = z[0], cx = z[1], cy = z[2];
+    /* constants of the kernel order (picles_hip.hip, picles_create) */
+    const double r_g = ph->r_g;
+    const double g4 = 0.25 * G0, g42 = g4 * g4, K = g42 * g42;
+    const double ie2 = k->inv_eT * k->inv_eT, inv_eT4 = ie2 * ie2;
+    const double rg2 = r_g * r_g, rg4 = rg2 * rg2, rg8 = rg4 * rg4;
+    const double Cw = (0.5 * G0) * r_g, Chrh = -0.25 * r_g;
+    const double ymax = 10.0 / r_g, sgmax = 1e8 / rg2;
+    const double KeT4y = (K * inv_eT4) * rg8, KrCay = ((K * r_g) * ph->C_alpha) * rg8;
+    const double Cs = (0.5 * ph->C_phi) * rg2, Cdir2 = 2.0 * ph->C_phi;
+    const double g4rg2 = g4 * rg2;
+    const double qU2r_max = 249999.0 / (ymax * ymax);
+
     double c2 = PO_FMA(cx, cx, cy * cy);
     double U2 = PO_FMA(u, u, v * v);
-    /* rc = 1/c_gp = r_g/|c̄| via the shared deterministic rsqrt; the reference's speed floors
-     * (0.1, 1e-4) become ceilings on rc (10, 1e4); a NaN rc (|c̄| = 0) takes the guarded branch */
-    double rc = ph->r_g * o_rsqrt(c2);
-    double minv = fmin(rc, 10.0);            /* IEEE minNum: a NaN rc gives the floor */
-    double wp = (0.5 * G0) * minv;
-    double m2 = minv * minv;                 /* k_p = (g/4) m2: its powers are taken on m2, K = (g/4)⁴ rides in the constants */
-    double rc2 = rc * rc;
-    double alpha2 = fmin((0.25 * U2) * rc2, 250000.0);   /* α² = min(U/(2 c_gp), 500)²: the wind speed itself is never formed */
-    /* dot / cross products on the raw c̄; the 1/r_g factors ride in the constants */
+    double qU2r = (0.25 * U2) * rg2;
+    double y = o_rsqrt(c2);                 /* a NaN y (|c̄| = 0, inf or NaN) is not plain and takes the ceilings (IEEE minNum) */
+    double y2 = y * y;
     double dotc = PO_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
-    double sginv2 = fmin(rc2, 1e8);
-    double ap = ((0.5 * k->inv_rg) * dotc) * sginv2;
-    double ya = ap - 0.85;
+    int plain = (U2 >= 1e-290 && qU2r <= qU2r_max) && (y <= ymax);
+    double ym = fmin(y, ymax);              /* the identity for a plain particle, like the next three */
+    double wp = Cw * ym;
+    double aph = (Chrh * dotc) * fmin(y2, sgmax);      /* -α_p/2 */
+    if (!plain) {   /* beyond ±699 the exponential below underflows in its second power either way (same H, Δ): the kernels clamp, a NaN stays */
+        aph = (aph > 699.0) ? 699.0 : aph;
+        aph = (aph < -699.0) ? -699.0 : aph;
+    }
+    double m2 = ym * ym;
+    double m4 = m2 * m2;
+    double yh = aph + 0.425;                /* -ya/2, ya = α_p - 0.85 (exact halving) */
     /* one reciprocal for H_β and Δ_β: r = 1/(hp (1+t)²), H = (1+t)² r, Δ = 1 - 5t hp r */
     double hp, t, H, rHD, t12;
     if (k->p == 0.75) {
-        /* 2p = 3/2: eH = exp(-2p ya) = w^(±3) and t = exp(-20|ya|) = w^40 with w = exp(-|ya|/2); s = w³, hp = 1 + s,
-         * H = 1/(1+s) for ya >= 0 and s/(1+s) below (physics.h rhs3) */
-        double w = o_exp(-0.5 * fabs(ya));
+        /* 2p = 3/2: eH = exp(-2p ya) = w^(±3) and t = exp(-20|ya|) = w^40 with w = exp(-|ya|/2) = exp(-|yh|); s = w³, hp = 1 + s,
+         * H = 1/(1+s) for ya >= 0 and s/(1+s) below; the powers along 1, 2, 3, 5, 10, 20, 40 (physics.h rhs3) */
+        double w = o_exp(-fabs(yh));
         double w2 = w * w, s3 = w2 * w;
-        double w4 = w2 * w2, w5 = w4 * w, w10 = w5 * w5, w20 = w10 * w10;
+        double w5 = s3 * w2, w10 = w5 * w5, w20 = w10 * w10;
         t = w20 * w20;
         hp = 1.0 + s3;
         double t1 = 1.0 + t;
         t12 = t1 * t1;
         rHD = 1.0 / (hp * t12);
-        H = (t12 * rHD) * ((ya >= 0.0) ? 1.0 : s3);
+        H = (t12 * rHD) * ((yh <= 0.0) ? 1.0 : s3);
     } else {
         /* general p: t = exp(-20|ya|) is taken as 0 once 5t < 2^-54 (Δ rounds to 1); eH stays finite (argument <= 700) */
+        double ya = -2.0 * yh;
         double harg = (-2.0 * k->p) * ya;
         hp = 1.0 + o_exp((harg > 700.0) ? 700.0 : harg);
         double targ = -20.0 * fabs(ya);
@@ -363,38 +390,34 @@ static void po_rhs_kernel(const po_model *M, int64_t idx, const double z[5], dou
     }
     double D = PO_FMA(-((5.0 * t) * hp), rHD, 1.0);
 
-    double aH = alpha2 * H;
-    int n_is_2 = (k->n == 2.0);
-    /* constants of the kernel order (picles_hip.hip, picles_create) */
-    const double g4 = 0.25 * G0, g42 = g4 * g4, K = g42 * g42;
-    const double ie2 = k->inv_eT * k->inv_eT, inv_eT4 = ie2 * ie2;
-    const double KeT4 = K * inv_eT4, KrCa = (K * ph->r_g) * ph->C_alpha;
-    const double Cdir = ph->C_phi * (2.0 * (k->inv_rg * k->inv_rg));
-    double Ek8 = 0.0;
-    if ((ph->dissipation && n_is_2) || ph->peak_shift) {
-        double m4 = m2 * m2;
-        Ek8 = o_exp(2.0 * lne) * (m4 * m4);
+    double y2H = y2 * H;
+    double aH, Sd = 0.0;
+    if (plain) {
+        aH = qU2r * y2H;                                             /* α² H, α² = (U²/4) r_g² y² below its cap */
+        if (ph->direction) Sd = ((crsc * dotc) * (y2 * y2H)) * Cs;   /* the wind speed cancels: no 1/U² */
+    } else {
+        aH = fmin(qU2r * y2, 250000.0) * H;                          /* α² = min(U/(2 c_gp), 500)² */
+        if (ph->direction && !(U2 == 0.0 || c2 == 0.0)) Sd = ((crsc * dotc) * (y2 * aH)) * (Cdir2 * (1.0 / U2));
     }
+    if (ph->direction) {   /* opt-in dead band (picles_phys.dir_deadband) */
+        double db2 = ph->dir_deadband * ph->dir_deadband;
+        if (db2 > 0.0 && crsc * crsc <= db2 * (U2 * c2)) Sd = 0.0;
+    }
+    int n_is_2 = (k->n == 2.0);
+    double Ek8 = 0.0;
+    if ((ph->dissipation && n_is_2) || ph->peak_shift) Ek8 = o_exp_sat(lne + lne) * (m4 * m4);
     double Dt = 0.0;
     if (ph->dissipation) {
         if (n_is_2) {
-            Dt = Ek8 * KeT4;
+            Dt = Ek8 * KeT4y;
         } else {
-            double ke = (g4 * m2) * k->inv_eT;
+            double ke = (g4rg2 * m2) * k->inv_eT;
             Dt = o_exp(k->n * lne) * o_pow(ke, 2.0 * k->n);
         }
     }
     double IDt = PO_FMA(ph->input ? ph->C_e : 0.0, aH, -Dt);
     double wrS = 0.0;
-    if (ph->peak_shift) wrS = (wp * D) * (Ek8 * KrCa);
-    double Sd = 0.0;
-    if (ph->direction) {
-        if (!(U2 == 0.0 || c2 == 0.0)) Sd = ((crsc * dotc) * (rc2 * aH)) * (Cdir * (1.0 / U2));
-        {   /* opt-in dead band (picles_phys.dir_deadband) */
-            double db2 = ph->dir_deadband * ph->dir_deadband;
-            if (db2 > 0.0 && crsc * crsc <= db2 * (U2 * c2)) Sd = 0.0;
-        }
-    }
+    if (ph->peak_shift) wrS = (wp * D) * (Ek8 * KrCay);
     if (M->pc) Sd = Sd + cx * M->pc[idx];   /* great-circle term rides on the direction term */
     dz[0] = PO_FMA(wp, IDt, wrS);
     dz[1] = PO_FMA(cy, Sd, -(cx * wrS));

@@ -33,6 +33,14 @@ struct KParams {
     double p, n, neg2p, inv_eT;
     double inv_eT4, half_inv_rg, two_inv_rg2;   /* (1/e_T)⁴, 1/(2 r_g), 2/r_g² */
     double KeT4, KrCa, Cdir;                    /* K/e_T⁴, K r_g C_α with K = (g/4)⁴ (k_p⁴ = K·(1/c_gp)⁸); 2 C_φ/r_g² */
+    /* the RHS works on y = 1/|c̄| (1/c_gp = r_g y): every power of r_g rides in a constant (rhs3) */
+    double rg2;                                 /* r_g² */
+    double Cw, Chrh;                            /* ω_p = Cw·min(y, ymax), Cw = (g/2) r_g;  -α_p/2 = (Chrh·c̄·u)·min(y², sgmax), Chrh = -r_g/4 */
+    double ymax, sgmax;                         /* 10/r_g, 1e8/r_g²: the reference's speed floors 0.1 and 1e-4 as ceilings on y and y² */
+    double KeT4y, KrCay;                        /* KeT4 r_g⁸, KrCa r_g⁸ */
+    double Cs, Cdir2;                           /* C_φ r_g²/2 (direction term of a plain particle), 2 C_φ (… of a clamped one, times 1/U²) */
+    double g4rg2;                               /* (g/4) r_g²: k_p = g4rg2·min(y, ymax)² (general n) */
+    double qU2r_max;                            /* a plain wind has (U²/4) r_g² <= qU2r_max: α² = (U²/4) r_g² y² stays below 500² for every y <= ymax */
     double inv_dx, inv_dy;
     double deadband2;       /* dir_deadband² (0 = off) */
     int propagation, input, dissipation, peak_shift, direction, n_is_2;
@@ -263,36 +271,25 @@ struct PStats {
 /* node wind at absolute time t plus the quantities every RHS evaluation derives from it.
  * For time-constant winds they are computed once per particle-step (same arithmetic, hoisted). */
 struct WindD {
-    double u, v, U2, invU2, qU2;   /* U² = u²+v², 1/U², U²/4 — the wind speed itself is never needed (α enters as α²) */
-    double sK;                     /* 2 C_φ/(r_g² U²): the wind's share of the direction term */
+    double u, v;
+    double qU2r;                   /* (U²/4) r_g²: α² = qU2r y² — the wind speed itself is never needed (α enters as α²) */
+    double sh;                     /* pm_exp's shifter in a vector register pair (PM_EXP_SHIFTER(), set once by the integrator) */
+    double ymaxw;                  /* WAVE-uniform: ymax where every lane's wind is plain (wind_is_plain), -1 otherwise — so that the
+                                    * one test "every lane has y <= ymaxw" of rhs3 covers the wind as well */
 };
+/* a PLAIN wind: U² an ordinary positive number and small enough that α = U/(2 c_gp) cannot reach its cap of 500 while c_gp is above its
+ * floor (y <= ymax); with a plain y as well (rhs3) none of the reference's guards acts on the particle */
+PM_HD bool wind_is_plain(const KParams &P, double U2, double qU2r) { return U2 >= 1e-290 && qU2r <= P.qU2r_max; }
 PM_HD void wind_derive(const KParams &P, double u, double v, WindD &d)
 {
     d.u = u;
     d.v = v;
-    d.U2 = PM_FMA(u, u, v * v);
-    d.invU2 = 1.0 / d.U2;
-    d.qU2 = 0.25 * d.U2;
-    d.sK = P.Cdir * d.invU2;
+    const double U2 = PM_FMA(u, u, v * v);       /* recomputed from (u, v) where a rare path needs it: not kept */
+    d.qU2r = (0.25 * U2) * P.rg2;
+    d.ymaxw = PM_WAVE_ALL(wind_is_plain(P, U2, d.qU2r)) ? P.ymax : -1.0;
 }
-/* the same for the stage winds of a time-varying window (seven times per RK attempt): 1/U² through the plain-range reciprocal
- * — the bits of the division for a normal operand far from the ends of the exponent range, 7 issue slots instead of the IEEE
- * expansion's 11 — behind a wave-uniform range test; a calm (U² = 0), subnormal or non-finite lane sends the wave through the
- * division itself */
-PM_HD void wind_derive_stage(const KParams &P, double u, double v, WindD &d)
-{
-    d.u = u;
-    d.v = v;
-    d.U2 = PM_FMA(u, u, v * v);
-    if (PM_WAVE_ALL(d.U2 >= 1e-290 && d.U2 <= 1e290)) {
-        d.invU2 = pm_rcp_plain(d.U2);
-    } else {
-        PM_RARE_PATH();
-        d.invU2 = 1.0 / d.U2;
-    }
-    d.qU2 = 0.25 * d.U2;
-    d.sK = P.Cdir * d.invU2;
-}
+/* the same for the stage winds of a time-varying window (seven times per RK attempt) */
+PM_HD void wind_derive_stage(const KParams &P, double u, double v, WindD &d) { wind_derive(P, u, v, d); }
 PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double &v)
 {
     if (P.wind_static) {
@@ -379,6 +376,24 @@ PM_HD void index_weight(double zp, int &b, double &w_hi)
     w_hi = pm_div_1e6(__builtin_rint((zp - fb) * 1e6));      /* the bits of rint(...) / 1e6 */
 }
 
+/* Rare paths read their parameters afresh from the kernarg segment: the Rosenbrock23 attempt and the guarded forms of rhs3
+ * (every kernel that reaches them — k_step, k_advance — takes KParams as its FIRST argument).
+ * The Rosenbrock23 attempt reads its parameters afresh from the kernarg segment (every kernel that reaches it — k_step, k_advance —
+ * takes KParams as its FIRST argument).  The branch is entered by a minority of attempts, but what it alone needs — C_φ, 2/r_g²,
+ * 1/e_T⁴, C_α, the unfolded constants of the Jacobian — would otherwise sit in scalar registers through all seven Tsit5 stages of
+ * every attempt; the scalar file overflows there and its spill code (v_readlane / v_writelane) is VALU work inside the loop.
+ * Behind an opaque copy of the segment pointer the loads stay inside the branch (scalar loads, K$ hits). */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const KParams &ros_params(const KParams &)
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    __asm__ volatile("" : "+s"(p));
+    return *(const KParams *)p;
+}
+#else
+PM_HD const KParams &ros_params(const KParams &P) { return P; }
+#endif
+
 /* RHS in kernel order: d(lne), d(c̄x), d(c̄y).  The position tendencies are c̄x/Δx, c̄y/Δy
  * (linear in the state, independent of x,y) and are folded into the stepper.
  * FAST = all five physics switches on and n == 2 (every reference script). */
@@ -390,43 +405,65 @@ template <bool FAST, bool METRIC = false>
 PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD &W, Vec3 &d, double pc = 0.0)
 {
     const double u = W.u, v = W.v;
-    double c2 = PM_FMA(cx, cx, cy * cy);
-    /* rc = 1/c_gp = r_g/|c̄| through the deterministic reciprocal square root (no sqrt, no division).
-     * Every use of rc passes a guard written so that a NaN (|c̄| = 0, inf or NaN) takes the guarded
-     * branch: the speed floors 0.1 / 1e-4 of the reference become ceilings 10 / 1e4 on rc. */
-    double rc = P.r_g * pm_rsqrt(c2);
-    double minv = pm_fmin_c(rc, 10.0);
-    double wp = (0.5 * PK_G0) * minv;
-    double m2 = minv * minv;                            /* k_p = (g/4)·m2; its powers are taken on m2, the constant rides below */
-    double rc2 = rc * rc;
-    double alpha2 = pm_fmin_c(W.qU2 * rc2, 250000.0);     /* α² = min(U/(2 c_gp), 500)² */
-    /* dot and cross products on the raw c̄ (the 1/r_g factors ride in the constants below);
-     * the cross product is two rounded products and one subtraction: exactly 0 for c̄x = c̄y, u = v */
-    double dotc = PM_FMA(u, cx, v * cy);
-    double crsc = u * cy - v * cx;
-    double sginv2 = pm_fmin_c(rc2, 1e8);      /* = (rc <= 1e4) ? rc² : 1e8, NaN -> 1e8 */
-    double ap = (P.half_inv_rg * dotc) * sginv2;
-    double ya = ap - 0.85;
+    const double c2 = PM_FMA(cx, cx, cy * cy);
+    /* y = 1/|c̄| through the deterministic reciprocal square root (no sqrt, no division); 1/c_gp = r_g y, and every power of r_g
+     * rides in a constant.  The reference's guards — the speed floors 0.1 (ω_p, k_p) and 1e-4 (α_p) = ceilings ymax, sgmax on y, y²;
+     * the cap α <= 500; the zero tests of the direction term — are the identity for a PLAIN particle: y <= ymax under a plain wind
+     * (wind_is_plain).  Where every lane of the wave is plain — one compare and a scalar branch — none of them is evaluated; the
+     * rare path evaluates them lane by lane (a NaN y, |c̄| = 0, inf or NaN, is not plain and takes the guarded forms).  The plain
+     * values are computed first and overwritten on the rare path (no copies on the common one). */
+    const double y = pm_rsqrt(c2);
+    const double y2 = y * y;
+    /* dot and cross products on the raw c̄; the cross product is two rounded products and one subtraction: exactly 0 for
+     * c̄x = c̄y, u = v */
+    const double dotc = PM_FMA(u, cx, v * cy);
+    const double crsc = u * cy - v * cx;
+    const bool plain = PM_WAVE_ALL(y <= W.ymaxw);
+    double wp = P.Cw * y;                    /* ω_p = (g/2) r_g min(y, ymax) */
+    double aph = (P.Chrh * dotc) * y2;       /* -α_p/2 = -(r_g/4)(c̄·u) min(y², sgmax) */
+    double m2 = y2;                          /* min(y, ymax)²: k_p = (g/4) r_g² m2 */
+    double m4 = y2 * y2;
+    bool y_plain = true;
+    if (!plain) {
+        PM_RARE_PATH();
+        const KParams &R = ros_params(P);    /* ymax, sgmax, ...: loaded here, not held in scalar registers through the loop */
+        y_plain = (y <= R.ymax);
+        const double ym = pm_fmin(y, R.ymax);
+        wp = R.Cw * ym;
+        aph = (R.Chrh * dotc) * pm_fmin(y2, R.sgmax);
+        /* beyond ±699 the exponential below underflows in its second power either way (w² = 0: s = t = 0, H and Δ the same bits):
+         * clamped (a NaN stays), so that it never needs a range test */
+        aph = (aph > 699.0) ? 699.0 : aph;
+        aph = (aph < -699.0) ? -699.0 : aph;
+        m2 = ym * ym;
+        m4 = m2 * m2;
+        PM_RARE_VALUE(wp); PM_RARE_VALUE(aph); PM_RARE_VALUE(m4);
+        if (!FAST) PM_RARE_VALUE(m2);
+    }
+    /* yh = -ya/2 = -α_p/2 + 0.425 (the halving is exact): w = exp(-|ya|/2) = exp(-|yh|).  |yh| <= 700 always: for a plain particle
+     * |α_p/2| = (r_g/4)|c̄·u| y² <= (r_g/4) U ymax <= 250 whatever r_g is (that is what qU2r_max says); the others were clamped above */
+    const double yh = aph + 0.425;
     /* H_β = 1/(1+eH), eH = exp(-2p ya);  Δ_β = 1 - 1.25 sech²(10 ya) = 1 - 5t/(1+t)², t = exp(-20|ya|).
      * One reciprocal serves both: r = 1/(hp (1+t)²), H = (1+t)² r, Δ = 1 - 5t hp r. */
     double hp, t, H, rHD, t12;
     if (FAST || P.p_is_075) {
-        /* 2p = 3/2: both exponentials are powers of w = exp(-|ya|/2) — eH = w^(±3), t = w^40 — so ONE exponential and seven
-         * multiplications serve both (the second exponential cost 16 issue slots).  With s = w³ <= 1: for ya >= 0, eH = s and
-         * H = 1/(1+s); for ya < 0, eH = 1/s and H = s/(1+s): the reciprocal is that of hp = 1 + s in [1, 2] either way, and Δ,
-         * which depends on t alone, keeps its form.  For 20|ya| >= 40, 5t < 2^-54: 1 + t and Δ round to exactly 1. */
-        double w = pm_exp(-0.5 * pm_fabs(ya));
+        /* 2p = 3/2: both exponentials are powers of w = exp(-|ya|/2) — eH = w^(±3), t = w^40 — so ONE exponential and six
+         * multiplications (1, 2, 3, 5, 10, 20, 40) serve both.  With s = w³ <= 1: for ya >= 0, eH = s and H = 1/(1+s); for ya < 0,
+         * eH = 1/s and H = s/(1+s): the reciprocal is that of hp = 1 + s in [1, 2] either way, and Δ, which depends on t alone,
+         * keeps its form.  For 20|ya| >= 40, 5t < 2^-54: 1 + t and Δ round to exactly 1. */
+        const double w = pm_exp_negabs_inrange(yh, W.sh);
         double w2 = w * w, s3 = w2 * w;
-        double w4 = w2 * w2, w5 = w4 * w, w10 = w5 * w5, w20 = w10 * w10;
+        double w5 = s3 * w2, w10 = w5 * w5, w20 = w10 * w10;
         t = w20 * w20;
         hp = 1.0 + s3;
         double t1 = 1.0 + t;
         t12 = t1 * t1;
         rHD = pm_rcp_plain(hp * t12);            /* a plain operand in [1, 8] (or NaN) */
-        H = (t12 * rHD) * ((ya >= 0.0) ? 1.0 : s3);
+        H = (t12 * rHD) * ((yh <= 0.0) ? 1.0 : s3);
     } else {
         /* general p: two exponentials.  For 20|ya| >= 40 t is taken as 0 (no exp), which also makes H = 1/(1+eH) to the last
          * bit; eH is kept finite so that 0·eH stays 0 */
+        const double ya = -2.0 * yh;
         hp = 1.0 + pm_exp_finite(P.neg2p * ya);
         double targ = -20.0 * pm_fabs(ya);
         t = 0.0;
@@ -437,49 +474,47 @@ PM_HD void rhs3(const KParams &P, double lne, double cx, double cy, const WindD 
         H = t12 * rHD;
     }
     double D = PM_FMA(-((5.0 * t) * hp), rHD, 1.0);
-    const double aH = alpha2 * H;
-    /* e² k_p⁴ / K = e² (1/c_gp)⁸, K = (g/4)⁴: shared by the dissipation and the peak shift, which carry K in their constants */
-    double Ek8 = 0.0;
-    if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) {
-        double m4 = m2 * m2;
-        Ek8 = pm_exp(2.0 * lne) * (m4 * m4);
+    /* α² H = (U²/4) r_g² y² H and the direction term S_dir = C_φ α² H sin 2(θ_c - θ_w), sin 2(θ_c - θ_w) = 2 (c̄ × u)(c̄ · u) y²/U²:
+     * for a plain particle the wind speed cancels, S_dir = (C_φ r_g²/2)·(c̄ × u)(c̄ · u)·y²·(y² H) — no reciprocal of U² on the path
+     * (the stage winds of a time-varying window paid one per stage).  A particle that is not plain (rare path, lane by lane) takes
+     * the capped α² and the guarded form with 1/U²: 0 for a vanishing wind or c̄. */
+    const double y2H = y2 * H;
+    double aH = W.qU2r * y2H;
+    double Sd = 0.0;
+    if (FAST || P.direction) Sd = ((crsc * dotc) * (y2 * y2H)) * P.Cs;
+    if (!plain) {
+        PM_RARE_PATH();
+        const KParams &R = ros_params(P);
+        const double U2 = PM_FMA(u, u, v * v);
+        if (!(y_plain && wind_is_plain(R, U2, W.qU2r))) {
+            aH = pm_fmin(W.qU2r * y2, 250000.0) * H;         /* α² = min(U/(2 c_gp), 500)² */
+            if (FAST || P.direction)
+                Sd = (U2 == 0.0 || PM_FMA(cx, cx, cy * cy) == 0.0) ? 0.0 : ((crsc * dotc) * (y2 * aH)) * (R.Cdir2 * (1.0 / U2));
+        }
     }
+    /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned.  Only the general-physics
+     * kernels carry it (a run-time test here costs the specialised kernel 2.6 %, measured; a compile-time flavour of it
+     * doubled the kernel count): a context with a dead band runs the general kernels */
+    if (!FAST && P.direction && P.deadband2 > 0.0) {
+        if (crsc * crsc <= P.deadband2 * (PM_FMA(u, u, v * v) * PM_FMA(cx, cx, cy * cy))) Sd = 0.0;
+    }
+    /* e² k_p⁴ / (K r_g⁸) = e² min(y, ymax)⁸, K = (g/4)⁴: shared by the dissipation and the peak shift, which carry K r_g⁸ in their constants */
+    double Ek8 = 0.0;
+    if (FAST || (P.dissipation && P.n_is_2) || P.peak_shift) Ek8 = pm_exp_sat(lne + lne, W.sh) * (m4 * m4);
     /* Ĩ - D̃ = C_e α² H - e² k_p⁴/e_T⁴ in one fused step (a switched-off term is an exact zero: C_e -> 0, D̃ -> 0) */
     double Dt = 0.0;
     if (FAST || P.dissipation) {
         if (FAST || P.n_is_2) {
-            Dt = Ek8 * P.KeT4;
+            Dt = Ek8 * P.KeT4y;
         } else {
-            double ke = ((0.25 * PK_G0) * m2) * P.inv_eT;
+            double ke = (P.g4rg2 * m2) * P.inv_eT;
             Dt = pm_exp(P.n * lne) * pm_pow(ke, 2.0 * P.n);
         }
     }
     const double IDt = PM_FMA((FAST || P.input) ? P.C_e : 0.0, aH, -Dt);
     /* ω_p r_g S_cg = ω_p r_g C_α Δ e² k_p⁴ */
     double wrS = 0.0;
-    if (FAST || P.peak_shift) wrS = (wp * D) * (Ek8 * P.KrCa);
-    double Sd = 0.0;
-    if (FAST || P.direction) {
-        /* S_dir = C_φ α² H sin 2(θ_c - θ_w) = [2 C_φ/(r_g² U²)]·(c̄ × u)(c̄ · u)·(1/c_gp²)·α² H; 0 for a vanishing wind or c̄ */
-        /* (the guard behind a wave-uniform test: a compare and a scalar branch where every lane has a wind and a c̄ — the normal
-         * case — instead of a compare and two selects; same bits either way) */
-        /* (the guard behind a wave-uniform test on the product — zero when either factor is, or when both are below 1e-162: the rare
-         * path repeats the exact test — one multiplication, one compare and a scalar branch where every lane has a wind and a c̄
-         * instead of two compares and two selects; same bits either way) */
-        const double Sd_ = ((crsc * dotc) * (rc2 * aH)) * W.sK;
-        if (PM_WAVE_ALL(!(W.U2 * c2 == 0.0))) {
-            Sd = Sd_;
-        } else {
-            PM_RARE_PATH();
-            if (!(W.U2 == 0.0 || c2 == 0.0)) Sd = Sd_;
-        }
-        /* opt-in dead band: sin²(θ_c-θ_w) = crs²/(U c_gp)² below dir_deadband² counts as aligned.  Only the general-physics
-         * kernels carry it (a run-time test here costs the specialised kernel 2.6 %, measured; a compile-time flavour of it
-         * doubled the kernel count): a context with a dead band runs the general kernels */
-        if (!FAST && P.deadband2 > 0.0) {
-            if (crsc * crsc <= P.deadband2 * (W.U2 * c2)) Sd = 0.0;
-        }
-    }
+    if (FAST || P.peak_shift) wrS = (wp * D) * (Ek8 * P.KrCay);
     if (METRIC) Sd = Sd + cx * pc;   /* great-circle term S_sphere = PC(c̄x) = c̄x·coef rides on S_dir */
     d.lne = PM_FMA(wp, IDt, wrS);
     d.cx = PM_FMA(cy, Sd, -(cx * wrS));
@@ -514,7 +549,16 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     double wp = (0.5 * PK_G0) * minv;
     double kp = (0.25 * PK_G0) * (minv * minv);
     double rc2 = rc * rc;
-    double a2 = W.qU2 * rc2;
+    const double W_U2 = PM_FMA(u, u, v * v);
+    const double W_qU2 = 0.25 * W_U2;
+    double W_invU2;                                  /* 1/U²: the bits of the division (plain-range reciprocal behind a wave-uniform range test) */
+    if (PM_WAVE_ALL(W_U2 >= 1e-290 && W_U2 <= 1e290)) {
+        W_invU2 = pm_rcp_plain(W_U2);
+    } else {
+        PM_RARE_PATH();
+        W_invU2 = 1.0 / W_U2;
+    }
+    double a2 = W_qU2 * rc2;
     double alpha2 = pm_fmin(a2, 250000.0);
     double dotc = PM_FMA(u, cx, v * cy);
     double crsc = u * cy - v * cx;
@@ -525,7 +569,7 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
      * exponential serves both when 2p = 3/2 */
     double hp, t, t1, t12, rHD, H, gH;
     if (FAST || P.p_is_075) {
-        double w = pm_exp(-0.5 * pm_fabs(ya));
+        double w = pm_exp_sh(-0.5 * pm_fabs(ya), W.sh);
         double w2 = w * w, s3 = w2 * w;
         double w4 = w2 * w2, w5 = w4 * w, w10 = w5 * w5, w20 = w10 * w10;
         t = w20 * w20;
@@ -553,18 +597,18 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     double aH = alpha2 * H;
     const bool n2 = FAST || P.n_is_2;
     const bool s_in = FAST || P.input, s_di = FAST || P.dissipation, s_ps = FAST || P.peak_shift, s_dr = FAST || P.direction;
-    double E2 = pm_exp(2.0 * lne);
+    double E2 = pm_exp_sh(2.0 * lne, W.sh);
     double k2 = kp * kp, k4 = k2 * k2;
     double Ek = E2 * k4;
     double It = s_in ? P.C_e * aH : 0.0;
     double Dt = (s_di && n2) ? Ek * P.inv_eT4 : 0.0;
     if (s_di && !n2) Dt = pm_exp(P.n * lne) * pm_pow(kp * P.inv_eT, 2.0 * P.n);
     double Scg = s_ps ? (P.C_alpha * D) * Ek : 0.0;
-    bool calm = (W.U2 == 0.0 || c2 == 0.0);
-    double rU = rc2 * W.invU2;
+    bool calm = (W_U2 == 0.0 || c2 == 0.0);
+    double rU = rc2 * W_invU2;
     double cd = (P.two_inv_rg2 * crsc) * dotc;
     double s2 = calm ? 0.0 : cd * rU;
-    bool dead = !FAST && (P.deadband2 > 0.0 && crsc * crsc <= P.deadband2 * (W.U2 * c2));
+    bool dead = !FAST && (P.deadband2 > 0.0 && crsc * crsc <= P.deadband2 * (W_U2 * c2));
     if (dead) s2 = 0.0;
     double Sd = s_dr ? (P.C_phi * aH) * s2 : 0.0;
     double wrS = (wp * P.r_g) * Scg;
@@ -579,8 +623,8 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
         double drc2 = 2.0 * (rc * drc);
         double dU2 = 2.0 * PM_FMA(u, du, v * dv);
         double dqU2 = 0.25 * dU2;
-        double dinvU2 = -((W.invU2 * W.invU2) * dU2);
-        double dalpha2 = (a2 <= 250000.0) ? PM_FMA(W.qU2, drc2, rc2 * dqU2) : 0.0;
+        double dinvU2 = -((W_invU2 * W_invU2) * dU2);
+        double dalpha2 = (a2 <= 250000.0) ? PM_FMA(W_qU2, drc2, rc2 * dqU2) : 0.0;
         double ddot = PM_FMA(u, dcx, v * dcy) + PM_FMA(cx, du, cy * dv);
         double dcrs = (u * dcy - v * dcx) + (cy * du - cx * dv);
         double dsg = (rc2 <= 1e8) ? drc2 : 0.0;
@@ -599,7 +643,7 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
         double ds2 = 0.0;
         if (!calm && !dead) {
             double dcd = P.two_inv_rg2 * PM_FMA(dcrs, dotc, crsc * ddot);
-            double drU = PM_FMA(drc2, W.invU2, rc2 * dinvU2);
+            double drU = PM_FMA(drc2, W_invU2, rc2 * dinvU2);
             ds2 = PM_FMA(dcd, rU, cd * drU);
         }
         double dSd = s_dr ? P.C_phi * PM_FMA(daH, s2, aH * ds2) : 0.0;
@@ -610,22 +654,6 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
         df[q].cy = -(PM_FMA(dcx, Sdm, cx * dSd) + PM_FMA(dcy, wrS, cy * dwrS));
     }
 }
-
-/* The Rosenbrock23 attempt reads its parameters afresh from the kernarg segment (every kernel that reaches it — k_step, k_advance —
- * takes KParams as its FIRST argument).  The branch is entered by a minority of attempts, but what it alone needs — C_φ, 2/r_g²,
- * 1/e_T⁴, C_α, the unfolded constants of the Jacobian — would otherwise sit in scalar registers through all seven Tsit5 stages of
- * every attempt; the scalar file overflows there and its spill code (v_readlane / v_writelane) is VALU work inside the loop.
- * Behind an opaque copy of the segment pointer the loads stay inside the branch (scalar loads, K$ hits). */
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ const KParams &ros_params(const KParams &)
-{
-    auto p = __builtin_amdgcn_kernarg_segment_ptr();
-    __asm__ volatile("" : "+s"(p));
-    return *(const KParams *)p;
-}
-#else
-PM_HD const KParams &ros_params(const KParams &P) { return P; }
-#endif
 
 /* one attempted Rosenbrock23 step of size h from (z, f0) at absolute time t: returns EEst² (kernel-order norm),
  * un = the new state, f2 = f(un, t+h) (the next step's FSAL), eig = ||J||_inf */
@@ -814,6 +842,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     const double ipy = (FAST || P.propagation) ? (METRIC ? m22 : P.inv_dy) : 0.0;
     Vec3 k1, k2, k3, k4, k5, k6, k7;
     WindD W;
+    W.sh = PM_EXP_SHIFTER();
     DP_TAB_DECL(TSIT ? 1 : 0);
     constexpr bool has2 = TSIT;   /* Tsit5: a72, e2 != 0 (compile-time: the DP5 instruction stream is untouched) */
     constexpr double beta1 = TSIT ? PI_BETA1_TSIT : PI_BETA1, beta2 = TSIT ? PI_BETA2_TSIT : PI_BETA2;
@@ -969,12 +998,13 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
         /* PI controller in log space (kernel order): 1/q = γ·qold^β2 / EEst^β1, clamped to
          * [qmin, qmax]; lq = ln(qold) is the carried controller memory. One log + one exp per step. */
         double le = 0.5 * pm_log_coarse(EE2);
-        bool accept = (EE2 <= 1.0) || (P.force_dtmin && h <= P.dtmin);
+        /* (force_dtmin as a threshold, -1 when off — h > 0: a scalar double instead of a lane mask held across the loop) */
+        bool accept = (EE2 <= 1.0) || (h <= (P.force_dtmin ? P.dtmin : -1.0));
         if (accept) {
             st.acc++;
-            double qi = pm_exp(PM_FMA(beta2, lq, -(beta1 * le))) * PI_GAMMA;
-            qi = pm_fmax_c(pm_fmin_c(qi, PI_QMAX), PI_QMIN);
-            lq = pm_fmax_c(le, PI_LNQOLDINIT);
+            double qi = pm_exp_sat(PM_FMA(beta2, lq, -(beta1 * le)), W.sh) * PI_GAMMA;   /* clamped to [qmin, qmax] right below: saturation is the identity here */
+            qi = pm_fmax_c(pm_fmin_c(qi, PM_SCI(PI_QMAX)), PM_SCI(PI_QMIN));   /* the bounds created at their use (two s_mov): as loop invariants they were spilled scalars */
+            lq = pm_fmax_c(le, PM_SCI(PI_LNQOLDINIT));
             dt = h * qi;
             z = un;
                     k1 = k7;
@@ -982,10 +1012,10 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             if (z.lne != z.lne || z.cx != z.cx || z.cy != z.cy || z.x != z.x || z.y != z.y) break;
         } else {
             st.rej++;
-            double r = PI_GAMMA * pm_exp(-(beta1 * le));
-            r = pm_fmax_c(r, PI_QMIN);
+            double r = PI_GAMMA * pm_exp_inrange(-(beta1 * le), W.sh);   /* |le| <= 355 (pm_log_coarse of a number in [0, inf]) */
+            r = pm_fmax_c(r, PM_SCI(PI_QMIN));
             dt = h * r;
-            if (!P.force_dtmin && h <= P.dtmin) { st.status |= 64 /*PICLES_ST_DTMIN*/; break; }
+            if (h <= (P.force_dtmin ? -1.0 : P.dtmin)) { st.status |= 64 /*PICLES_ST_DTMIN*/; break; }
         }
     }
     dtn = dt;

@@ -612,6 +612,19 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
         P.KeT4 = K * P.inv_eT4;
         P.KrCa = (K * P.r_g) * P.C_alpha;
         P.Cdir = P.C_phi * P.two_inv_rg2;
+        /* the y = 1/|c̄| form of the RHS (physics.h rhs3): the powers of r_g in the constants */
+        P.rg2 = P.r_g * P.r_g;
+        const double rg4 = P.rg2 * P.rg2, rg8 = rg4 * rg4;
+        P.Cw = (0.5 * PK_G0) * P.r_g;
+        P.Chrh = -0.25 * P.r_g;
+        P.ymax = 10.0 / P.r_g;
+        P.sgmax = 1e8 / P.rg2;
+        P.KeT4y = P.KeT4 * rg8;
+        P.KrCay = P.KrCa * rg8;
+        P.Cs = (0.5 * P.C_phi) * P.rg2;
+        P.Cdir2 = 2.0 * P.C_phi;
+        P.g4rg2 = k1 * P.rg2;
+        P.qU2r_max = 249999.0 / (P.ymax * P.ymax);
     }
     P.inv_dx = 1.0 / g->dx; P.inv_dy = 1.0 / g->dy;
     P.deadband2 = p->dir_deadband * p->dir_deadband;

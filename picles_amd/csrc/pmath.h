@@ -97,6 +97,37 @@ __device__ __forceinline__ double pm_sc(double c)
 PM_HD double pm_sc(double c) { return c; }
 #endif
 
+/* The same with the two s_mov written out (PM_SCI(literal)): pm_sc pins the VALUE, but the compiler still creates the halves of
+ * its operand where it likes — for a constant whose low dword is zero it shares a zero register and keeps the high dword as a loop
+ * invariant, which under scalar register pressure is a spilled one (v_readlane + v_writelane per use, measured in the accept path
+ * of the step-size controller).  Here both halves are created by the asm itself, at the use. */
+#if defined(__HIP_DEVICE_COMPILE__)
+template <unsigned long long BITS>
+__device__ __forceinline__ double pm_sci_(void)
+{
+    unsigned lo, hi;
+    __asm__ volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"((unsigned)(BITS & 0xffffffffull)), "n"((unsigned)(BITS >> 32)));
+    return pm_from_bits(((uint64_t)hi << 32) | lo);
+}
+#define PM_SCI(c) pm_sci_<__builtin_bit_cast(unsigned long long, (double)(c))>()
+#else
+#define PM_SCI(c) (c)
+#endif
+
+/* A constant kept in a VECTOR register pair: an instruction reads at most one scalar operand, so of the two constants of
+ * fma(x, 512/ln2, shifter) one has to be a vector register; left to itself the compiler re-creates it at some of its uses (s_mov,
+ * s_mov, v_mov_b64: one issue slot each time).  Behind a side-effect-free asm the value is an ordinary loop-invariant: created once,
+ * shared by every use (the asm statements are identical and merge).  Identity on the host. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double pm_vc(double c)
+{
+    __asm__("" : "+v"(c));
+    return c;
+}
+#else
+PM_HD double pm_vc(double c) { return c; }
+#endif
+
 /* 2^k for -1022 <= k <= 1023 */
 PM_HD double pm_pow2i(int k) { return pm_from_bits((uint64_t)(k + 1023) << 52); }
 
@@ -157,17 +188,21 @@ __device__ __forceinline__ double *pm_lds_tab(void)
     __shared__ double tab[PM_EXP_N];
     return tab;
 }
+/* The LDS copy is BIASED: entry j holds 2^(j/512) with (j << 11) subtracted from its high dword, so that the exponent m and the
+ * index j of ki = 512 m + j are put back by ONE integer instruction, hi + (ki << 11) = hi(2^(j/512)) + (m << 20) — the high dword of
+ * 2^m 2^(j/512) (pm_exp_plain below; v_lshl_add_u32 in place of a shift and a v_ldexp_f64). */
+__device__ __forceinline__ double pm_tab_bias(double t, unsigned j) { return pm_from_bits(pm_bits(t) - ((uint64_t)(j << 11) << 32)); }
 __device__ __forceinline__ void pm_device_init(void)
 {
     /* 256 threads per workgroup in every kernel that calls this (not blockDim.x: that is a load from the dispatch packet, and with
      * the trip count known both table loads are in flight together): two entries per thread */
     static_assert(PM_EXP_N == 512, "two table entries per thread of a 256-thread workgroup");
     const double t0 = PM_EXP_TAB_C[threadIdx.x], t1 = PM_EXP_TAB_C[threadIdx.x + 256];
-    pm_lds_tab()[threadIdx.x] = t0;
-    pm_lds_tab()[threadIdx.x + 256] = t1;
+    pm_lds_tab()[threadIdx.x] = pm_tab_bias(t0, threadIdx.x);
+    pm_lds_tab()[threadIdx.x + 256] = pm_tab_bias(t1, threadIdx.x + 256);
     __syncthreads();
 }
-#define PM_EXP_TAB(j) (pm_lds_tab()[(j)])
+#define PM_EXP_TAB(j) (pm_from_bits(pm_bits(pm_lds_tab()[(j)]) + ((uint64_t)((unsigned)(j) << 11) << 32)))   /* the entry itself (rare paths) */
 #else
 static const double PM_EXP_TAB_H[PM_EXP_N] = PM_EXP_TAB_INIT;
 #define PM_EXP_TAB(j) (PM_EXP_TAB_H[(j)])
@@ -181,6 +216,18 @@ __device__ __forceinline__ void pm_device_init(void) {}   /* host pass of hipcc:
 /* core: x already inside [-746, 710] (or NaN).
  * x = (512 m + j) ln2/512 + r, |r| <= ln2/1024; exp(x) = 2^m * 2^(j/512) * (1 + r P3(r)); the truncation error
  * r^5/120 <= 1.2e-18 is far below the rounding of the final product. */
+/* expm1(r) = r + r² (1/2 + r/6 + r²/24) for |r| <= ln2/1024, in Estrin's form: four issue slots like Horner's, but every
+ * instruction has at most ONE constant that is not an inline operand — on the device it rides in scalar registers (pm_sc), where
+ * Horner's first step fma(1/24, r, 1/6) wants one of its two in a vector register pair (kept for the whole kernel, or copied at
+ * every use) — and the dependent chain is one step shorter */
+PM_HD double pm_expm1_poly(double r)
+{
+    const double r2 = r * r;
+    const double a = PM_FMA(r, pm_sc(1.6666666666666666e-01), 0.5);
+    const double b = PM_FMA(r2, pm_sc(4.1666666666666664e-02), a);
+    return PM_FMA(r2, b, r);
+}
+
 PM_HD double pm_exp_core(double x)
 {
     /* k = rint(x 512/ln2) through the shifter 1.5·2^52: the sum is rounded to an integer by the addition itself (round to nearest
@@ -193,11 +240,7 @@ PM_HD double pm_exp_core(double x)
     int ki = (int)(uint32_t)pm_bits(kd);
     int j = ki & (PM_EXP_N - 1);
     int m = ki >> PM_EXP_SHIFT;
-    double p = 4.1666666666666664e-02;                /* 1/4! */
-    p = PM_FMA(p, r, 1.6666666666666666e-01);         /* 1/3! */
-    p = PM_FMA(p, r, 0.5);
-    p = PM_FMA(p, r, 1.0);
-    double q = p * r;                                 /* expm1(r): small, so T + T q rounds once */
+    double q = pm_expm1_poly(r);                      /* expm1(r): small, so T + T q rounds once */
     double T = PM_EXP_TAB(j);
     return __builtin_ldexp(PM_FMA(T, q, T), m);
 }
@@ -207,21 +250,66 @@ PM_HD double pm_exp_core(double x)
  * normal case); the result is the same bit pattern either way. */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PM_WAVE_ALL(c) __all(c)
-#define PM_RARE_PATH() asm volatile("")   /* keeps the rare path a real branch (no if-conversion into selects) */
+#define PM_RARE_PATH() asm volatile("; PM_RARE_PATH")   /* keeps the rare path a real branch (no if-conversion into selects); the comment marks it for scripts/isa_budget.py */
+/* a value computed on a rare path, made opaque: the optimiser cannot merge the rare expression with the common one it replaces
+ * (it would turn "compute, then overwrite on the rare path" into a select of the operands and a copy on the common path) */
+#define PM_RARE_VALUE(x) asm volatile("" : "+v"(x))
 #else
 #define PM_WAVE_ALL(c) (c)
 #define PM_RARE_PATH() ((void)0)
+#define PM_RARE_VALUE(x) ((void)0)
 #endif
 
-PM_HD double pm_exp(double x)
+#if defined(__HIP_DEVICE_COMPILE__)
+/* exp(x), x = -|a| if NEGABS else a, for |x| <= 700 (or a NaN): the bits of pm_exp_core(x) in fewer issue slots.
+ *  - 2^m enters through the high dword of the (biased) table entry — one v_lshl_add_u32 — before the last fma instead of a shift
+ *    and a v_ldexp_f64 after it: for a normal result (|x| <= 700) scaling by 2^m commutes with that rounding;
+ *  - NEGABS: the sign and the absolute value ride on the operands of the two instructions that read x (source modifiers), so
+ *    exp(-|a|) costs what exp(a) costs.
+ * tests/test_gpu_pmath.py holds both forms against the host's pm_exp bit for bit. */
+template <bool NEGABS>
+__device__ __forceinline__ double pm_exp_plain(double a, double sh)   /* sh: the shifter in a vector register pair (PM_EXP_SHIFTER()) */
+{
+    const double x = NEGABS ? -__builtin_fabs(a) : a;
+    /* kd = fma(x, 512/ln2, shifter), written out: the three-address form with the shifter read in place (the compiler's
+     * two-address v_fmac copies it first) */
+    double kd;
+    if (NEGABS) __asm__("v_fma_f64 %0, -|%1|, %2, %3" : "=v"(kd) : "v"(a), "s"(PM_EXP_RN), "v"(sh));
+    else __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(kd) : "v"(a), "s"(PM_EXP_RN), "v"(sh));
+    const double k = kd - 6755399441055744.0;
+    double r;
+    if (NEGABS) __asm__("v_fma_f64 %0, -%1, %2, -|%3|" : "=v"(r) : "v"(k), "s"(PM_EXP_LHI), "v"(a));   /* |a| is never a value of its own */
+    else r = PM_FMA(-k, PM_EXP_LHI, x);
+    r = PM_FMA(-k, PM_EXP_LLO, r);
+    const uint32_t ki = (uint32_t)pm_bits(kd);
+    const double q = pm_expm1_poly(r);
+    const uint64_t tb = pm_bits(pm_lds_tab()[ki & (PM_EXP_N - 1)]);
+    uint32_t hi;
+    __asm__("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(hi) : "v"(ki), "n"(20 - PM_EXP_SHIFT), "v"((uint32_t)(tb >> 32)));
+    const double T = __hiloint2double((int)hi, (int)(uint32_t)tb);
+    return PM_FMA(T, q, T);
+}
+#endif
+
+/* The callers inside the Runge-Kutta loop create the shifter once (PM_EXP_SHIFTER(): an opaque, loop-invariant vector register
+ * pair) and hand it to every exponential; the one-argument forms create their own.  The host ignores it. */
+#define PM_EXP_SHIFTER() pm_vc(6755399441055744.0)
+
+PM_HD double pm_exp_sh(double x, double sh)
 {
     if (!PM_WAVE_ALL(pm_fabs(x) <= 700.0)) {
         PM_RARE_PATH();
         x = (x > 710.0) ? 710.0 : x;
         x = (x < -746.0) ? -746.0 : x;
+        return pm_exp_core(x);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return pm_exp_plain<false>(x, sh);
+#else
     return pm_exp_core(x);
+#endif
 }
+PM_HD double pm_exp(double x) { return pm_exp_sh(x, PM_EXP_SHIFTER()); }
 
 /* exp(min(x, 700)): never overflows (callers that multiply the result by a possible zero) */
 PM_HD double pm_exp_finite(double x)
@@ -230,13 +318,54 @@ PM_HD double pm_exp_finite(double x)
         PM_RARE_PATH();
         x = (x > 700.0) ? 700.0 : x;
         x = (x < -746.0) ? -746.0 : x;
+        return pm_exp_core(x);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return pm_exp_plain<false>(x, PM_EXP_SHIFTER());
+#else
     return pm_exp_core(x);
+#endif
 }
 
 /* exp(x) for callers that guarantee |x| <= 700 or x NaN: same bits as pm_exp, no clamps
  * (a NaN reaches the table through a masked index and propagates through the polynomial) */
+#if defined(__HIP_DEVICE_COMPILE__)
+PM_HD double pm_exp_bounded(double x) { return pm_exp_plain<false>(x, PM_EXP_SHIFTER()); }
+#else
 PM_HD double pm_exp_bounded(double x) { return pm_exp_core(x); }
+#endif
+
+/* exp(-|a|) for a caller that guarantees |a| <= 700 (or a NaN): the bits of pm_exp(-fabs(a)), no range test */
+PM_HD double pm_exp_negabs_inrange(double a, double sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return pm_exp_plain<true>(a, sh);
+#else
+    return pm_exp_core(-pm_fabs(a));
+#endif
+}
+/* exp(x) for a caller that guarantees |x| <= 700 (or a NaN), shifter handed in */
+PM_HD double pm_exp_inrange(double x, double sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return pm_exp_plain<false>(x, sh);
+#else
+    return pm_exp_core(x);
+#endif
+}
+/* SATURATING exponential exp(min(max(x, -700), 700)): in [1e-304, 1e304], never 0, denormal or inf; a NaN propagates.  For the
+ * right-hand side, where e² beyond e^±700 has no meaning either way: the out-of-range side is two selects in front of the SAME
+ * evaluation (no second copy of the exponential behind the range test, as pm_exp has for its ldexp form) */
+PM_HD double pm_exp_sat(double x, double sh)
+{
+    if (!PM_WAVE_ALL(pm_fabs(x) <= 700.0)) {
+        PM_RARE_PATH();
+        x = (x > 700.0) ? 700.0 : x;
+        x = (x < -700.0) ? -700.0 : x;
+        PM_RARE_VALUE(x);
+    }
+    return pm_exp_inrange(x, sh);
+}
 
 /* log(x), branch-free main path (fdlibm style: x = 2^k (1+f), s = f/(2+f),
  * log(1+f) = f - hfsq + s (hfsq + R(s^2))), special cases selected at the end */
@@ -276,6 +405,19 @@ PM_HD double pm_log(double x)
     return res;
 }
 
+/* fma(a, b, a) as ONE three-address v_fma_f64.  The seed of pm_rsqrt is (0, hi) with the zero a register shared by every seed
+ * in the kernel: the compiler's two-address form (v_fmac) would first copy the pair — one more issue slot per reciprocal root. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double pm_fma_aba(double a, double b)
+{
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+PM_HD double pm_fma_aba(double a, double b) { return PM_FMA(a, b, a); }
+#endif
+
 /* x^y for x > 0 (fetch-relation seeding and e_T only) */
 /* 1/sqrt(x) for x > 0 (normal range), ~1 ulp, from +, *, fma and integer ops only — the same bits on
  * the host and on the device (the hardware v_rsq/v_rcp approximations are not reproducible on a CPU,
@@ -287,7 +429,7 @@ PM_HD double pm_rsqrt(double x)
     double y = pm_from_bits((uint64_t)hi << 32);
     const double hx = 0.5 * x;
     double e;
-    e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);
+    e = PM_FMA(-hx, y * y, 0.5); y = pm_fma_aba(y, e);     /* y + y e */
     e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);
     e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);
     e = PM_FMA(-hx, y * y, 0.5); y = PM_FMA(y, e, y);

@@ -47,8 +47,22 @@ def classify(ins):
     return "other:" + ins.split()[0]
 
 
+_ASM = {}
+
+
+def assembly(unit):
+    """the compiler's assembly of a translation unit (compiled once per process)"""
+    if unit not in _ASM:
+        _ASM[unit] = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", str(SRC / unit), "-o", "-"], capture_output=True, text=True, cwd=SRC, timeout=1200).stdout
+    return _ASM[unit]
+
+
+def kernels(unit):
+    return [m.group(1) for m in re.finditer(r"^(_Z\d+k_(?:step|advance)I\w*):\s*;", assembly(unit), re.M)]
+
+
 def budget(unit, prefix, verbose=False):
-    asm = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", str(SRC / unit), "-o", "-"], capture_output=True, text=True, cwd=SRC, timeout=1200).stdout
+    asm = assembly(unit)
     heads = list(re.finditer(r"^(_Z\d+k_(?:step|advance)I\w*):\s*;", asm, re.M))
     sel = [(m, nxt) for m, nxt in zip(heads, heads[1:] + [None]) if m.group(1).startswith(prefix)]
     assert len(sel) == 1, [m.group(1) for m, _ in sel]
@@ -79,27 +93,42 @@ def budget(unit, prefix, verbose=False):
             blocks.append(cur)
             continue
         t = l.strip()
+        if cur is not None and "PM_RARE_PATH" in t:
+            cur["ins"].append("@rare")          # the marker PM_RARE_PATH() leaves in the assembly
+            continue
         if cur is None or not t or t.startswith((";", ".", "//")):
             continue
         cur["ins"].append(t.split(";")[0].strip())
-    # instructions that the stream skips with a wave-uniform branch placed right before them (s_cbranch_scc* to the NEXT label: the
-    # form PM_WAVE_ALL / PM_RARE_PATH compile to) are a rare path: split off into a block of their own, listed, and left out of the
-    # common-path totals
+    # instructions that the stream skips with a wave-level forward branch (the form PM_WAVE_ALL / PM_RARE_PATH compile to) and that
+    # carry the PM_RARE_PATH marker are a rare path: split off into blocks of their own, listed, and left out of the common-path
+    # totals.  The skipped stretch may span several labelled blocks (an exec-masked region inside the rare path).
+    order = {b["label"]: k for k, b in enumerate(blocks)}
+    rare_from = {}          # block index -> instruction index from which the block is rare (0: the whole block)
+    for k, b in enumerate(blocks):
+        for q, ins in enumerate(b["ins"]):
+            mm = re.match(r"s_cbranch_(?:scc[01]|vccn?z)\s+\.(LBB\d+_\d+)", ins)
+            if not mm or mm.group(1) not in order or order[mm.group(1)] <= k:
+                continue
+            tgt = order[mm.group(1)]
+            skipped = b["ins"][q + 1:] + [i for bb in blocks[k + 1:tgt] for i in bb["ins"]]
+            if "@rare" in skipped and tgt - k <= 16:
+                rare_from.setdefault(k, q + 1)
+                for kk in range(k + 1, tgt):
+                    rare_from[kk] = 0
     split = []
     for k, b in enumerate(blocks):
-        nxt_label = blocks[k + 1]["label"] if k + 1 < len(blocks) else None
-        cut = None
-        for q, ins in enumerate(b["ins"]):
-            mm = re.match(r"s_cbranch_scc[01]\s+\.(LBB\d+_\d+)", ins)
-            if mm and mm.group(1) == nxt_label and q + 1 < len(b["ins"]):
-                cut = q + 1
-                break
-        b["rare"] = False
-        if cut is None:
+        if k not in rare_from:
+            b["rare"] = False
+            split.append(b)
+        elif rare_from[k] == 0:
+            b["rare"] = True
             split.append(b)
         else:
+            cut = rare_from[k]
             split.append({"label": b["label"], "hdr": b["hdr"], "ins": b["ins"][:cut], "rare": False})
             split.append({"label": b["label"] + "+", "hdr": b["hdr"], "ins": b["ins"][cut:], "rare": True})
+    for b in split:
+        b["ins"] = [i for i in b["ins"] if i != "@rare"]
     blocks = split
     prod = Counter()
     for b in blocks:

@@ -11,8 +11,9 @@
 #include <vector>
 #include "pmath.h"
 
-enum { F_RCP, F_DIV, F_DIV1E6, F_EXP, F_LOG, F_LOGC, F_RSQRT, F_N };
-static const char *NAMES[F_N] = {"pm_rcp_plain", "pm_div_plain", "pm_div_1e6", "pm_exp", "pm_log", "pm_log_coarse", "pm_rsqrt"};
+enum { F_RCP, F_DIV, F_DIV1E6, F_EXP, F_LOG, F_LOGC, F_RSQRT, F_EXPP, F_EXPS, F_EXPNI, F_EXPI, F_N };
+static const char *NAMES[F_N] = {"pm_rcp_plain", "pm_div_plain", "pm_div_1e6", "pm_exp", "pm_log", "pm_log_coarse", "pm_rsqrt",
+                                 "pm_exp(in range)", "pm_exp_sat", "pm_exp_negabs_inrange", "pm_exp_inrange"};
 
 PM_HD double apply(int fn, double a, double b)
 {
@@ -23,6 +24,13 @@ PM_HD double apply(int fn, double a, double b)
     case F_EXP: return pm_exp(a);
     case F_LOG: return pm_log(a);
     case F_LOGC: return pm_log_coarse(a);
+    // the plain-range forms of the exponential (device: pm_exp_plain — the 2^m through the biased table entry, the sign and the
+    // absolute value as source modifiers); a wave takes them only when ALL its lanes are in range, so these operands come in
+    // runs of 64: F_EXPP, F_EXPNI and F_EXPI all in range, F_EXPS (the saturating form) every second wave mixed with out-of-range operands
+    case F_EXPP: return pm_exp(a);
+    case F_EXPS: return pm_exp_sat(a, PM_EXP_SHIFTER());
+    case F_EXPNI: return pm_exp_negabs_inrange(a, PM_EXP_SHIFTER());
+    case F_EXPI: return pm_exp_inrange(a, PM_EXP_SHIFTER());
     default: return pm_rsqrt(a);
     }
 }
@@ -72,7 +80,16 @@ int main()
             case F_DIV1E6: a[i] = (double)(i % 1000001); b[i] = 0.0; break;
             case F_EXP: a[i] = (kind == 0) ? -746.0 + 1456.0 * u01(g) : ((kind == 1) ? -40.0 * u01(g) : 20.0 * (u01(g) - 0.5)); b[i] = 0.0; break;
             case F_LOG: case F_LOGC: a[i] = (kind == 0) ? std::fabs(pow2(g, -1022, 1023)) : ((kind == 1) ? 1.0 + 0.6 * (u01(g) - 0.5) : std::exp(60.0 * (u01(g) - 0.5))); b[i] = 0.0; break;
-            default: a[i] = (kind == 0) ? std::fabs(pow2(g, -1000, 1000)) : 1e-3 + 400.0 * u01(g); b[i] = 0.0; break;
+            case F_EXPP: a[i] = (kind == 0) ? -700.0 + 1400.0 * u01(g) : ((kind == 1) ? -40.0 * u01(g) : ((kind == 2) ? 20.0 * (u01(g) - 0.5) : pow2(g, -60, 8))); b[i] = 0.0; break;
+            case F_EXPS:
+                if (((i >> 6) & 1) == 0) a[i] = (kind == 0) ? -700.0 + 1400.0 * u01(g) : ((kind == 1) ? 250.0 * (u01(g) - 0.5) : pow2(g, -60, 8));
+                else a[i] = (kind == 0) ? -760.0 + 1520.0 * u01(g) : ((kind == 1) ? pow2(g, 9, 40) : 250.0 * (u01(g) - 0.5));
+                if ((i & 1023) == 77) a[i] = (i & 1024) ? 0.0 : -0.0;
+                b[i] = 0.0;
+                break;
+            case F_EXPI: a[i] = (kind == 0) ? -700.0 + 1400.0 * u01(g) : ((kind == 1) ? -40.0 * u01(g) : ((kind == 2) ? 20.0 * (u01(g) - 0.5) : pow2(g, -1022, 8))); b[i] = 0.0; break;
+            case F_EXPNI: a[i] = (kind == 0) ? -700.0 + 1400.0 * u01(g) : ((kind == 1) ? 250.0 * (u01(g) - 0.5) : ((kind == 2) ? pow2(g, -1022, 8) : 2.0 * (u01(g) - 0.5))); b[i] = 0.0; break;
+            case F_RSQRT: default: a[i] = (kind == 0) ? std::fabs(pow2(g, -1000, 1000)) : 1e-3 + 400.0 * u01(g); b[i] = 0.0; break;
             }
         }
         CK(hipMemcpy(da, a.data(), N * 8, hipMemcpyHostToDevice));
