@@ -984,6 +984,116 @@ static void po_rhs_jvp(const po_model *M, int64_t idx, const double z[5], double
     }
 }
 
+/* the specialised physics of the kernels' FAST flavours: every switch on, n = 2, 2p = 3/2, no dead band (picles_hip.hip) */
+static int po_is_fast(const po_model *M)
+{
+    const picles_phys *ph = &M->ph;
+    return ph->propagation && ph->input && ph->dissipation && ph->peak_shift && ph->direction && M->k.n == 2.0 && M->k.p == 0.75 &&
+           ph->dir_deadband * ph->dir_deadband == 0.0;
+}
+
+/* is the particle PLAIN (po_rhs_kernel)?  y <= ymax under a wind with 1e-290 <= U² and (U²/4) r_g² <= qU2r_max */
+static int po_is_plain(const po_model *M, const double z[5], double u, double v)
+{
+    const double r_g = M->ph.r_g, rg2 = r_g * r_g, ymax = 10.0 / r_g;
+    const double U2 = PO_FMA(u, u, v * v), qU2r = (0.25 * U2) * rg2;
+    const double y = o_rsqrt(PO_FMA(z[1], z[1], z[2] * z[2]));
+    return (U2 >= 1e-290 && qU2r <= 249999.0 / (ymax * ymax)) && (y <= ymax);
+}
+
+/* The Jacobian of the specialised-physics RHS for a plain particle, along the structure of the RHS (physics.h rhs3_jac_plain, same
+ * operations in the same order): f = (F, c̄y Sd - c̄x S, -(c̄x Sd + c̄y S)) with F, S = ω_p r_g S_cg, Sd = S_dir functions of
+ * (ln e, c² = |c̄|², c̄·u, c̄×u); nine partials and the chain rule.  J[r][c] = ∂f_r/∂u_c; dT = ∂f/∂t through the wind's slope (du, dv). */
+static void po_rhs_jac_plain(const po_model *M, int64_t idx, const double z[5], double u, double v, double du, double dv,
+                             int tvar, double J[3][3], double dT[3])
+{
+    const picles_phys *ph = &M->ph;
+    const po_consts *k = &M->k;
+    const double L = z[0], cx = z[1], cy = z[2];
+    const double r_g = ph->r_g;
+    const double g4 = 0.25 * G0, g42 = g4 * g4, K = g42 * g42;
+    const double ie2 = k->inv_eT * k->inv_eT, inv_eT4 = ie2 * ie2;
+    const double rg2 = r_g * r_g, rg4 = rg2 * rg2, rg8 = rg4 * rg4;
+    const double Cw = (0.5 * G0) * r_g, Chrh = -0.25 * r_g;
+    const double KeT4y = (K * inv_eT4) * rg8, KrCay = ((K * r_g) * ph->C_alpha) * rg8;
+    const double Cs = (0.5 * ph->C_phi) * rg2;
+    const double U2 = PO_FMA(u, u, v * v);
+    const double qU2r = (0.25 * U2) * rg2;
+    const double c2 = PO_FMA(cx, cx, cy * cy);
+    const double y = o_rsqrt(c2);
+    const double y2 = y * y;
+    const double dotc = PO_FMA(u, cx, v * cy);
+    const double crsc = u * cy - v * cx;
+    const double wp = Cw * y;
+    const double aph = (Chrh * dotc) * y2;
+    const double m4 = y2 * y2;
+    const double yh = aph + 0.425;
+    const double w = o_exp(-fabs(yh));
+    const double w2 = w * w, s3 = w2 * w;
+    const double w5 = s3 * w2, w10 = w5 * w5, w20 = w10 * w10;
+    const double t = w20 * w20;
+    const double hp = 1.0 + s3, t1 = 1.0 + t;
+    const double t12 = t1 * t1;
+    const double rHD = 1.0 / (hp * t12);
+    const double H = (t12 * rHD) * ((yh <= 0.0) ? 1.0 : s3);
+    const double D = PO_FMA(-((5.0 * t) * hp), rHD, 1.0);
+    const double DH = -3.0 * (H * (1.0 - H));
+    const double iq = hp * rHD;
+    const double DD = copysign(200.0 * ((t * (1.0 - t)) * (t1 * (iq * iq))), yh);
+    const double yh_dot = Chrh * y2, yh_c2 = -(aph * y2);
+    const double H_dot = DH * yh_dot, H_c2 = DH * yh_c2, D_dot = DD * yh_dot, D_c2 = DD * yh_c2;
+    const double alpha2 = qU2r * y2;
+    const double aH = alpha2 * H;
+    const double aH_dot = alpha2 * H_dot;
+    const double aH_c2 = alpha2 * PO_FMA(-y2, H, H_c2);
+    const double Ek8 = o_exp_sat(L + L) * (m4 * m4);
+    const double Dt = Ek8 * KeT4y;
+    const double IDt = PO_FMA(ph->C_e, aH, -Dt);
+    const double Q = wp * (Ek8 * KrCay);
+    const double S = Q * D;
+    const double wpDt = wp * Dt, wpCe = wp * ph->C_e;
+    const double F_L = 2.0 * (S - wpDt);
+    const double S_dot = Q * D_dot;
+    const double F_dot = PO_FMA(wpCe, aH_dot, S_dot);
+    const double S_c2 = PO_FMA(Q, D_c2, -4.5 * (y2 * S));
+    const double F_c2 = PO_FMA(-0.5 * y2, wp * IDt, PO_FMA(4.0 * y2, wpDt, PO_FMA(wpCe, aH_c2, S_c2)));
+    const double Ba = Cs * m4;
+    const double B = Ba * H;
+    const double Pcd = crsc * dotc;
+    const double Sd = Pcd * B;
+    const double PBa = Pcd * Ba;
+    const double Sd_crs = dotc * B;
+    const double Sd_dot = PO_FMA(PBa, H_dot, crsc * B);
+    const double Sd_c2 = PBa * PO_FMA(-2.0 * y2, H, H_c2);
+    const double ax = cx + cx, ay = cy + cy;
+    const double F_x = PO_FMA(ax, F_c2, u * F_dot), F_y = PO_FMA(ay, F_c2, v * F_dot);
+    const double S_x = PO_FMA(ax, S_c2, u * S_dot), S_y = PO_FMA(ay, S_c2, v * S_dot);
+    double Sd_x = PO_FMA(ax, Sd_c2, PO_FMA(u, Sd_dot, -(v * Sd_crs)));
+    const double Sd_y = PO_FMA(ay, Sd_c2, PO_FMA(v, Sd_dot, u * Sd_crs));
+    double Sdm = Sd;
+    if (M->pc) { Sdm = Sd + cx * M->pc[idx]; Sd_x = Sd_x + M->pc[idx]; }
+    const double S_L = S + S;
+    J[0][0] = F_L; J[0][1] = F_x; J[0][2] = F_y;
+    J[1][0] = -(cx * S_L);
+    J[1][1] = PO_FMA(cy, Sd_x, -PO_FMA(cx, S_x, S));
+    J[1][2] = PO_FMA(cy, Sd_y, Sdm) - cx * S_y;
+    J[2][0] = -(cy * S_L);
+    J[2][1] = -(PO_FMA(cx, Sd_x, Sdm) + cy * S_x);
+    J[2][2] = -PO_FMA(cx, Sd_y, PO_FMA(cy, S_y, S));
+    dT[0] = dT[1] = dT[2] = 0.0;
+    if (tvar) {
+        const double dot_t = PO_FMA(cx, du, cy * dv), crs_t = PO_FMA(cy, du, -(cx * dv));
+        const double U2_t = 2.0 * PO_FMA(u, du, v * dv);
+        const double F_U2 = wpCe * ((0.25 * rg2) * (y2 * H));
+        const double F_t = PO_FMA(F_dot, dot_t, F_U2 * U2_t);
+        const double S_t = S_dot * dot_t;
+        const double Sd_t = PO_FMA(Sd_dot, dot_t, Sd_crs * crs_t);
+        dT[0] = F_t;
+        dT[1] = PO_FMA(cy, Sd_t, -(cx * S_t));
+        dT[2] = -PO_FMA(cx, Sd_t, cy * S_t);
+    }
+}
+
 /* one attempted Rosenbrock23 step of size h from (u0, f0) at absolute time t; returns EEst^2 (kernel-order norm) and
  * the stiffness estimate ||J||_inf */
 static double po_ros23_try(const po_model *M, int64_t idx, const double u0[5], const double f0[5],
@@ -996,15 +1106,19 @@ static double po_ros23_try(const po_model *M, int64_t idx, const double u0[5], c
     po_wind(M, idx, t, &uw, &vw);
     double dudt = 0.0, dvdt = 0.0;
     po_wind_dt(M, idx, t, &dudt, &dvdt);
-    const double seeds[4][5] = {{1, 0, 0, 0, 0}, {0, 1, 0, 0, 0}, {0, 0, 1, 0, 0}, {0, 0, 0, dudt, dvdt}};
-    double fj[3], dfs[4][3] = {{0}};
     const int ns = M->wind_static ? 3 : 4;        /* static winds: dT = 0, its terms are not formed at all */
-    po_rhs_jvp(M, idx, u0, uw, vw, ns, seeds, fj, dfs);
+    double J[3][3], dT[3] = {0.0, 0.0, 0.0};      /* J[r][c] = d f_r / d u_c */
+    if (M->order == 1 && po_is_fast(M) && po_is_plain(M, u0, uw, vw)) {
+        /* kernel order, specialised physics, plain particle: the structured Jacobian */
+        po_rhs_jac_plain(M, idx, u0, uw, vw, dudt, dvdt, !M->wind_static, J, dT);
+    } else {
+        const double seeds[4][5] = {{1, 0, 0, 0, 0}, {0, 1, 0, 0, 0}, {0, 0, 1, 0, 0}, {0, 0, 0, dudt, dvdt}};
+        double fj[3], dfs[4][3] = {{0}};
+        po_rhs_jvp(M, idx, u0, uw, vw, ns, seeds, fj, dfs);
+        for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) J[r][c] = dfs[c][r];
+        dT[0] = dfs[3][0]; dT[1] = dfs[3][1]; dT[2] = dfs[3][2];
+    }
     st->rhs += ns;    /* counted like RHS evaluations (the reference's ForwardDiff pass costs about as much) */
-    /* J[r][c] = d f_r / d u_c */
-    double J[3][3];
-    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) J[r][c] = dfs[c][r];
-    const double dT[3] = {dfs[3][0], dfs[3][1], dfs[3][2]};
     {   /* ||J||_inf over the 5 rows (rows x, y hold 1/dx, 1/dy) */
         double m = 0.0;
         for (int r = 0; r < 3; r++) {
@@ -1941,6 +2055,17 @@ PO_EXPORT int32_t picles_oracle_integrate_auto(po_model *M, int64_t idx, double 
 PO_EXPORT void picles_oracle_rhs_jvp(po_model *M, const double z[5], double u, double v, const double seed[5],
                                      double f[3], double df[3])
 {
+    if (M->order == 1 && po_is_fast(M) && po_is_plain(M, z, u, v)) {
+        /* the structured Jacobian of the kernel order (what po_ros23_try uses for this particle), applied to the direction */
+        double J[3][3], dT[3], dz[5];
+        po_rhs_jac_plain(M, 0, z, u, v, seed[3], seed[4], 1, J, dT);
+        po_rhs_kernel(M, 0, z, u, v, dz);
+        for (int r = 0; r < 3; r++) {
+            f[r] = dz[r];
+            df[r] = ((J[r][0] * seed[0] + J[r][1] * seed[1]) + J[r][2] * seed[2]) + dT[r];
+        }
+        return;
+    }
     const double seeds[1][5] = {{seed[0], seed[1], seed[2], seed[3], seed[4]}};
     double d[1][3];
     po_rhs_jvp(M, 0, z, u, v, 1, seeds, f, d);

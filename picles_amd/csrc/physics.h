@@ -655,30 +655,154 @@ PM_HD void rhs3_jvp(const KParams &P, double lne, double cx, double cy, const Wi
     }
 }
 
+/* The Jacobian of the specialised-physics RHS for a PLAIN particle (rhs3: none of the reference's guards acts), written out along
+ * the structure of the RHS instead of pushed through it direction by direction.  (c̄x, c̄y) enter through three scalars only —
+ * c² = |c̄|², the dot and the cross product with the wind — besides their explicit places in the momentum equations:
+ *     F  = d ln e/dt  = ω_p (Ĩ - D̃) + ω_p r_g S_cg      F(L, c², c̄·u)            L = ln e
+ *     S  = ω_p r_g S_cg = Q Δ_β                           S(L, c², c̄·u)            Q = ω_p r_g C_α e² k_p⁴
+ *     Sd = S_dir = (C_φ r_g²/2)(c̄×u)(c̄·u) y⁴ H_β         Sd(c², c̄·u, c̄×u)        y = 1/|c̄|
+ *     f  = (F,  c̄y Sd - c̄x S,  -(c̄x Sd + c̄y S))
+ * so nine partials — of (F, S, Sd) with respect to (L, c², c̄·u, c̄×u), mostly logarithmic derivatives (y^k: -k/2 y² per unit c²;
+ * e²: 2 per unit L) — and the chain rule ∂/∂c̄x = 2 c̄x ∂/∂c² + u ∂/∂(c̄·u) - v ∂/∂(c̄×u), ∂/∂c̄y = 2 c̄y ∂/∂c² + v ∂/∂(c̄·u) + u ∂/∂(c̄×u)
+ * give all nine entries: about 180 issue slots where three (with ∂f/∂t: four) passes of the forward-mode rhs3_jvp took 370.  H_β and
+ * Δ_β depend on ya = α_p - 0.85 = -2 yh alone: dH/dya = 2p H (1 - H), dΔ/dya = 100 sgn(ya) t (1 - t)/(1 + t)³, and
+ * 1/(1 + t)³ = (1 + t)(hp r)² reuses the reciprocal r = 1/(hp (1 + t)²) the primal has (no second one).  TV: ∂f/∂t through the node
+ * wind's slope (du, dv) — for a plain particle U² enters F only (α² ∝ U²; it cancels out of S_dir).
+ * A particle that is not plain takes rhs3_jvp (rare path of ros23_try, lane by lane).  J row-major: J[3 r + c] = ∂f_r/∂u_c. */
+template <bool METRIC, bool TV>
+PM_HD double rhs3_jac_plain(const KParams &P, double L, double cx, double cy, const WindD &W, double pc, double du, double dv,
+                            double (&J)[9], Vec3 &dT)      /* returns y = 1/|c̄| (the caller's plain test) */
+{
+    const double u = W.u, v = W.v;
+    const double c2 = PM_FMA(cx, cx, cy * cy);
+    const double y = pm_rsqrt(c2);
+    const double y2 = y * y;                          /* 1/c²: the unit of the logarithmic derivatives with respect to c² */
+    const double dotc = PM_FMA(u, cx, v * cy);
+    const double crsc = u * cy - v * cx;
+    const double wp = P.Cw * y;
+    const double aph = (P.Chrh * dotc) * y2;
+    const double m4 = y2 * y2;
+    const double yh = aph + 0.425;
+    const double w = pm_exp_negabs_inrange(yh, W.sh);
+    const double w2 = w * w, s3 = w2 * w;
+    const double w5 = s3 * w2, w10 = w5 * w5, w20 = w10 * w10;
+    const double t = w20 * w20;
+    const double hp = 1.0 + s3, t1 = 1.0 + t;
+    const double t12 = t1 * t1;
+    const double rHD = pm_rcp_plain(hp * t12);
+    const double H = (t12 * rHD) * ((yh <= 0.0) ? 1.0 : s3);
+    const double D = PM_FMA(-((5.0 * t) * hp), rHD, 1.0);
+    /* derivatives with respect to yh = -ya/2:  dH/dyh = -2·(3/2) H (1 - H),  dΔ/dyh = 200 sgn(yh) t (1 - t)/(1 + t)³ */
+    const double DH = -3.0 * (H * (1.0 - H));
+    const double iq = hp * rHD;                       /* 1/(1 + t)² */
+    const double DD = __builtin_copysign(200.0 * ((t * (1.0 - t)) * (t1 * (iq * iq))), yh);
+    const double yh_dot = P.Chrh * y2, yh_c2 = -(aph * y2);
+    const double H_dot = DH * yh_dot, H_c2 = DH * yh_c2, D_dot = DD * yh_dot, D_c2 = DD * yh_c2;
+    const double alpha2 = W.qU2r * y2;
+    const double aH = alpha2 * H;
+    const double aH_dot = alpha2 * H_dot;
+    const double aH_c2 = alpha2 * PM_FMA(-y2, H, H_c2);             /* α² ∝ y²: -y² per unit c² */
+    const double Ek8 = pm_exp_sat(L + L, W.sh) * (m4 * m4);
+    const double Dt = Ek8 * P.KeT4y;
+    const double IDt = PM_FMA(P.C_e, aH, -Dt);
+    const double Q = wp * (Ek8 * P.KrCay);
+    const double S = Q * D;
+    const double wpDt = wp * Dt, wpCe = wp * P.C_e;
+    /* F */
+    const double F_L = 2.0 * (S - wpDt);
+    const double S_dot = Q * D_dot;
+    const double F_dot = PM_FMA(wpCe, aH_dot, S_dot);
+    const double S_c2 = PM_FMA(Q, D_c2, -4.5 * (y2 * S));            /* Q ∝ y⁹ */
+    /* ω_p ∝ y: -y²/2;  D̃ ∝ y⁸: -4 y² */
+    const double F_c2 = PM_FMA(-0.5 * y2, wp * IDt, PM_FMA(4.0 * y2, wpDt, PM_FMA(wpCe, aH_c2, S_c2)));
+    /* S_dir = (c̄×u)(c̄·u) Ba H,  Ba = (C_φ r_g²/2) y⁴ */
+    const double Ba = P.Cs * m4;
+    const double B = Ba * H;
+    const double Pcd = crsc * dotc;
+    const double Sd = Pcd * B;
+    const double PBa = Pcd * Ba;
+    const double Sd_crs = dotc * B;
+    const double Sd_dot = PM_FMA(PBa, H_dot, crsc * B);
+    const double Sd_c2 = PBa * PM_FMA(-2.0 * y2, H, H_c2);
+    /* chain rule */
+    const double ax = cx + cx, ay = cy + cy;
+    const double F_x = PM_FMA(ax, F_c2, u * F_dot), F_y = PM_FMA(ay, F_c2, v * F_dot);
+    const double S_x = PM_FMA(ax, S_c2, u * S_dot), S_y = PM_FMA(ay, S_c2, v * S_dot);
+    double Sd_x = PM_FMA(ax, Sd_c2, PM_FMA(u, Sd_dot, -(v * Sd_crs)));
+    const double Sd_y = PM_FMA(ay, Sd_c2, PM_FMA(v, Sd_dot, u * Sd_crs));
+    double Sdm = Sd;
+    if (METRIC) { Sdm = Sd + cx * pc; Sd_x = Sd_x + pc; }           /* great-circle term c̄x·coef rides on S_dir */
+    const double S_L = S + S;
+    J[0] = F_L; J[1] = F_x; J[2] = F_y;
+    J[3] = -(cx * S_L);
+    J[4] = PM_FMA(cy, Sd_x, -PM_FMA(cx, S_x, S));
+    J[5] = PM_FMA(cy, Sd_y, Sdm) - cx * S_y;
+    J[6] = -(cy * S_L);
+    J[7] = -(PM_FMA(cx, Sd_x, Sdm) + cy * S_x);
+    J[8] = -PM_FMA(cx, Sd_y, PM_FMA(cy, S_y, S));
+    if (TV) {
+        const double dot_t = PM_FMA(cx, du, cy * dv), crs_t = PM_FMA(cy, du, -(cx * dv));
+        const double U2_t = 2.0 * PM_FMA(u, du, v * dv);
+        const double F_U2 = wpCe * ((0.25 * P.rg2) * (y2 * H));      /* α² H per unit U² */
+        const double F_t = PM_FMA(F_dot, dot_t, F_U2 * U2_t);
+        const double S_t = S_dot * dot_t;
+        const double Sd_t = PM_FMA(Sd_dot, dot_t, Sd_crs * crs_t);
+        dT.lne = F_t;
+        dT.cx = PM_FMA(cy, Sd_t, -(cx * S_t));
+        dT.cy = -PM_FMA(cx, Sd_t, cy * S_t);
+    }
+    return y;
+}
+
 /* one attempted Rosenbrock23 step of size h from (z, f0) at absolute time t: returns EEst² (kernel-order norm),
  * un = the new state, f2 = f(un, t+h) (the next step's FSAL), eig = ||J||_inf */
 template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z, const Vec3 &f0, double t, double h,
                        double ipx, double ipy, double pc, Vec5 &un, Vec3 &f2, double &eig, PStats &st)
 {
-    constexpr int NS = STATIC ? 3 : 4;
-    Seed5 seeds[NS];
-    Vec3 dfs[NS];
-    seeds[0] = {1.0, 0.0, 0.0, 0.0, 0.0};
-    seeds[1] = {0.0, 1.0, 0.0, 0.0, 0.0};
-    seeds[2] = {0.0, 0.0, 1.0, 0.0, 0.0};
+    const bool tv = !STATIC && !P.wind_static;   /* a time-varying instantiation may run with static winds: no dT terms then */
+    double dudt = 0.0, dvdt = 0.0;
     if (!STATIC) {      /* du/dt, dv/dt of the window's interpolant at t: parabola (du + (2 s - 1) bu) / (tw1 - tw0); knot form: the segment's slope */
         const double s_ = (t - P.tw0) * P.inv_dtw;
-        seeds[NS - 1] = {0.0, 0.0, 0.0, wind_slope(P, w.du, w.bu, s_) * P.inv_dtw, wind_slope(P, w.dv, w.bv, s_) * P.inv_dtw};
+        dudt = wind_slope(P, w.du, w.bu, s_) * P.inv_dtw;
+        dvdt = wind_slope(P, w.dv, w.bv, s_) * P.inv_dtw;
     }
-    const bool tv = !STATIC && !P.wind_static;   /* a time-varying instantiation may run with static winds: no dT terms then */
     wind_stage<STATIC>(P, w, t, W);
-    rhs3_jvp<FAST, METRIC, NS>(P, z.lne, z.cx, z.cy, W, pc, seeds, dfs);
+    double Jm[9];
+    Vec3 dT = {0.0, 0.0, 0.0};
+    /* the specialised physics takes the structured Jacobian (rhs3_jac_plain); a lane whose particle is not plain — and every lane of
+     * the general-physics kernels — the forward-mode rhs3_jvp along the unit directions */
+    bool fwd = !FAST;
+    double yj = 0.0;
+    if (FAST) {
+        yj = rhs3_jac_plain<METRIC, !STATIC>(P, z.lne, z.cx, z.cy, W, pc, dudt, dvdt, Jm, dT);
+        fwd = !PM_WAVE_ALL(yj <= W.ymaxw);
+    }
+    if (fwd) {
+        if (FAST) PM_RARE_PATH();
+        constexpr int NS = STATIC ? 3 : 4;
+        Seed5 seeds[NS];
+        Vec3 dfs[NS];
+        seeds[0] = {1.0, 0.0, 0.0, 0.0, 0.0};
+        seeds[1] = {0.0, 1.0, 0.0, 0.0, 0.0};
+        seeds[2] = {0.0, 0.0, 1.0, 0.0, 0.0};
+        if (!STATIC) seeds[NS - 1] = {0.0, 0.0, 0.0, dudt, dvdt};
+        rhs3_jvp<FAST, METRIC, NS>(P, z.lne, z.cx, z.cy, W, pc, seeds, dfs);
+        bool mine = true;         /* this lane takes the forward-mode result */
+        if (FAST) mine = !(wind_is_plain(P, PM_FMA(W.u, W.u, W.v * W.v), W.qU2r) && yj <= P.ymax);
+        if (mine) {
+            /* J[r][c] = d f_r / d u_c = dfs[c].r */
+            Jm[0] = dfs[0].lne; Jm[1] = dfs[1].lne; Jm[2] = dfs[2].lne;
+            Jm[3] = dfs[0].cx; Jm[4] = dfs[1].cx; Jm[5] = dfs[2].cx;
+            Jm[6] = dfs[0].cy; Jm[7] = dfs[1].cy; Jm[8] = dfs[2].cy;
+            if (!STATIC) dT = dfs[NS - 1];
+        }
+    }
+    if (!tv) dT = {0.0, 0.0, 0.0};
     st.rhs += tv ? 4 : 3;
-    /* J[r][c] = d f_r / d u_c = dfs[c].r */
-    const double J00 = dfs[0].lne, J01 = dfs[1].lne, J02 = dfs[2].lne;
-    const double J10 = dfs[0].cx, J11 = dfs[1].cx, J12 = dfs[2].cx;
-    const double J20 = dfs[0].cy, J21 = dfs[1].cy, J22 = dfs[2].cy;
+    const double J00 = Jm[0], J01 = Jm[1], J02 = Jm[2];
+    const double J10 = Jm[3], J11 = Jm[4], J12 = Jm[5];
+    const double J20 = Jm[6], J21 = Jm[7], J22 = Jm[8];
     {
         double m = 0.0;
         m = pm_fmax(m, (pm_fabs(J00) + pm_fabs(J01)) + pm_fabs(J02));
@@ -707,8 +831,6 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
         o.x = PM_FMA(gx, q1, (b3)); o.y = PM_FMA(gy, q2, (b4));          \
     } while (0)
     const double f0x = z.cx * ipx, f0y = z.cy * ipy;
-    Vec3 dT = {0.0, 0.0, 0.0};
-    if (tv) dT = dfs[NS - 1];
     Vec5 k1, k2, k3;
     if (!tv) WSOLVE(f0.lne, f0.cx, f0.cy, f0x, f0y, k1);
     else WSOLVE(PM_FMA(g, dT.lne, f0.lne), PM_FMA(g, dT.cx, f0.cx), PM_FMA(g, dT.cy, f0.cy), f0x, f0y, k1);
