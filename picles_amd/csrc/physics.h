@@ -820,7 +820,13 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     const double A10 = W12 * W20 - W10 * W22, A11 = W00 * W22 - W02 * W20, A12 = W02 * W10 - W00 * W12;
     const double A20 = W10 * W21 - W11 * W20, A21 = W01 * W20 - W00 * W21, A22 = W00 * W11 - W01 * W10;
     const double det = PM_FMA(W00, A00, PM_FMA(W01, A10, W02 * A20));
-    const double idet = 1.0 / det;
+    double idet;                    /* 1/det: the bits of the division (plain-range reciprocal behind a wave-uniform range test) */
+    if (PM_WAVE_ALL(pm_fabs(det) >= 1e-290 && pm_fabs(det) <= 1e290)) {
+        idet = pm_rcp_plain(det);
+    } else {
+        PM_RARE_PATH();
+        idet = 1.0 / det;
+    }
     const double gx = g * ipx, gy = g * ipy;
 #define WSOLVE(b0, b1, b2, b3, b4, o)                                   \
     do {                                                                \

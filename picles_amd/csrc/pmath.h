@@ -223,8 +223,8 @@ __device__ __forceinline__ void pm_device_init(void) {}   /* host pass of hipcc:
 PM_HD double pm_expm1_poly(double r)
 {
     const double r2 = r * r;
-    const double a = PM_FMA(r, pm_sc(1.6666666666666666e-01), 0.5);
-    const double b = PM_FMA(r2, pm_sc(4.1666666666666664e-02), a);
+    const double a = PM_FMA(r, 1.6666666666666666e-01, 0.5);
+    const double b = PM_FMA(r2, 4.1666666666666664e-02, a);
     return PM_FMA(r2, b, r);
 }
 

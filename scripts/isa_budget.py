@@ -73,22 +73,20 @@ def budget(unit, prefix, verbose=False):
     for k, l in enumerate(body):
         mm = re.match(r"^\.(LBB\d+_\d+):", l)
         if mm:
+            # the INNERMOST loop the block belongs to: "in Loop: Header=BBx_y Depth=d" names it; a block that is itself a loop header
+            # ("This (Inner) Loop Header: Depth=d", on the label's line or among the comment lines under it) belongs to its own loop
             hdr = None
-            for q in range(k, min(k + 5, len(body))):
-                h = re.search(r"Header=(BB\d+_\d+) Depth=(\d+)", body[q])
+            for q in range(k, min(k + 8, len(body))):
+                if q > k and not body[q].strip().startswith(";"):
+                    break
+                h = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", body[q])
+                if h:
+                    hdr = (mm.group(1)[1:], int(h.group(1)))
+                    break
+                h = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", body[q])
                 if h:
                     hdr = (h.group(1), int(h.group(2)))
                     break
-                if q > k and not body[q].strip().startswith(";"):
-                    break
-            if hdr is None:     # "Parent Loop BBx_y Depth=1" lines of nested loops
-                for q in range(k, min(k + 6, len(body))):
-                    h = re.search(r"Parent Loop (BB\d+_\d+) Depth=1", body[q])
-                    if h:
-                        hdr = (h.group(1), 2)
-                        break
-                    if q > k and not body[q].strip().startswith(";"):
-                        break
             cur = {"label": mm.group(1), "hdr": hdr, "ins": []}
             blocks.append(cur)
             continue
@@ -130,9 +128,21 @@ def budget(unit, prefix, verbose=False):
     for b in split:
         b["ins"] = [i for i in b["ins"] if i != "@rare"]
     blocks = split
+    # the Runge-Kutta loop: the INNERMOST loop (no child loops) with the most fp64 products — since the tile queue the kernel body sits
+    # in a loop of its own, whose straight-line part (re-seeding, remesh, the guards) holds more products than one RK attempt
+    parents = set()
+    for k, l in enumerate(body):
+        mm = re.match(r"^\.(LBB\d+_\d+):", l)
+        if mm:
+            for q in range(k + 1, min(k + 40, len(body))):
+                if not body[q].strip().startswith(";"):
+                    break
+                if "Child Loop" in body[q]:
+                    parents.add(mm.group(1)[1:])
+                    break
     prod = Counter()
     for b in blocks:
-        if b["hdr"]:
+        if b["hdr"] and b["hdr"][0] not in parents:
             prod[b["hdr"][0]] += sum(bool(re.match(r"v_(fma|fmac|mul)_f64", i)) for i in b["ins"])
     rk = max(prod, key=prod.get)
     tot = Counter()

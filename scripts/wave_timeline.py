@@ -89,7 +89,10 @@ s4 = np.stack([ss[first[full] + k] for k in range(4)], axis=1)
 out["workgroup_end_spread_us"] = {"mean": float((e4.max(1) - e4.min(1)).mean()), "p90": float(np.percentile(e4.max(1) - e4.min(1), 90))}
 out["workgroup_start_spread_us"] = {"mean": float((s4.max(1) - s4.min(1)).mean())}
 out["rk_us_mean"] = float((en - pl).mean())
-busy = dur > 0.5 * (dur.max() + dur.min()) if shape == "cfg5" else np.ones_like(dur, dtype=bool)
+# busy / calm: the durations of a mixed launch are bimodal (a calm wave is a handful of memory round trips, a busy one an integration);
+# the cut is three times the calm mode (the median of the shorter half), not the mid-range: one straggler would move that
+busy = dur > 3.0 * np.median(np.sort(dur)[:max(1, dur.size // 2)]) if shape == "cfg5" else np.ones_like(dur, dtype=bool)
+out["duration_histogram_us"] = {f"{lo:g}-{hi:g}": int(((dur >= lo) & (dur < hi)).sum()) for lo, hi in zip([0, 5, 8, 10, 12, 15, 20, 30, 40, 50, 60, 80, 120], [5, 8, 10, 12, 15, 20, 30, 40, 50, 60, 80, 120, 1e9])}
 if shape == "cfg5":
     occ_b = [float(((st[busy] < hi) & (en[busy] > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
     occ_c = [float(((st[~busy] < hi) & (en[~busy] > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]

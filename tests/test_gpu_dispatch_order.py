@@ -37,14 +37,16 @@ def test_half_calm_run_files_a_permutation_with_busy_blocks_first():
     nblk = n * n // 256
     assert busy + calm == nblk and busy > 0 and 8 * calm >= nblk, (busy, calm)
     assert np.array_equal(np.sort(order), np.arange(nblk))
-    # a workgroup owns 256 consecutive nodes of the index space (x fastest): with 512 nodes per row, block 2j is the left half of
-    # row j — winds of 0.1 m/s below x0 = L/2, nobody on — and block 2j + 1 the right half, where the ramp starts
+    # a workgroup owns 64 columns x 4 rows (kernels.h rows_index; block b = 8 by + bx with 512 nodes per row): the strips bx < 4 lie
+    # in the left half — winds of 0.1 m/s below x0 = L/2, nobody on — the strips bx >= 4 on the ramp.  (The first and the last
+    # row are grid boundary — their particles are not stepped — but every block holds rows that are not.)
     on = m.backend.get_particles()[1]                                   # [x, y]
-    has_on = np.array([on[(b % 2) * 256:(b % 2 + 1) * 256, b // 2].any() for b in range(nblk)])
-    assert not has_on[0::2].any() and has_on[1::2].all()
-    # (the first and the last row are grid boundary: their particles are not stepped, whatever the wind)
-    assert set(order[:busy].tolist()) == set(range(3, nblk - 2, 2))
-    assert set(order[busy:].tolist()) == set(range(0, nblk, 2)) | {1, nblk - 1}
+    nbx = n // 64
+    has_on = np.array([on[64 * (b % nbx):64 * (b % nbx + 1), 4 * (b // nbx):4 * (b // nbx + 1)].any() for b in range(nblk)])
+    left = (np.arange(nblk) % nbx) < nbx // 2
+    assert not has_on[left].any() and has_on[~left].all()
+    assert set(order[:busy].tolist()) == set(np.flatnonzero(~left).tolist())
+    assert set(order[busy:].tolist()) == set(np.flatnonzero(left).tolist())
 
 
 def test_homogeneous_box_files_nothing():
