@@ -45,6 +45,10 @@ struct KParams {
     double deadband2;       /* dir_deadband² (0 = off) */
     int propagation, input, dissipation, peak_shift, direction, n_is_2;
     int p_is_075;           /* 2p = 3/2 (q = -1/4, every reference script): exp(-2p y) and exp(-20|y|) are powers of one exponential */
+    int fast_phys;          /* the specialised physics (every switch on, n = 2, 2p = 3/2, no dead band): what the FAST flavours are built for.
+                             * A general-physics kernel that runs it (the per-node-metric flavour of the stand-alone advance) must take the
+                             * same arithmetic wherever FAST chooses between FORMS — the Jacobian of the Rosenbrock23 attempt — or an observed
+                             * step (k_advance) and a fused one (k_step) of the same model would differ in the last bits */
     /* ODE settings */
     double abstol, reltol, dt0, dtmin;
     double inv_abstol;       /* 1/abstol: the error scale of a component that is exactly 0 */
@@ -772,9 +776,10 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     Vec3 dT = {0.0, 0.0, 0.0};
     /* the specialised physics takes the structured Jacobian (rhs3_jac_plain); a lane whose particle is not plain — and every lane of
      * the general-physics kernels — the forward-mode rhs3_jvp along the unit directions */
-    bool fwd = !FAST;
+    const bool structured = FAST || P.fast_phys;      /* by the PHYSICS, not by the flavour (KParams::fast_phys) */
+    bool fwd = !structured;
     double yj = 0.0;
-    if (FAST) {
+    if (structured) {
         yj = rhs3_jac_plain<METRIC, !STATIC>(P, z.lne, z.cx, z.cy, W, pc, dudt, dvdt, Jm, dT);
         fwd = !PM_WAVE_ALL(yj <= W.ymaxw);
     }
@@ -789,7 +794,7 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
         if (!STATIC) seeds[NS - 1] = {0.0, 0.0, 0.0, dudt, dvdt};
         rhs3_jvp<FAST, METRIC, NS>(P, z.lne, z.cx, z.cy, W, pc, seeds, dfs);
         bool mine = true;         /* this lane takes the forward-mode result */
-        if (FAST) mine = !(wind_is_plain(P, PM_FMA(W.u, W.u, W.v * W.v), W.qU2r) && yj <= P.ymax);
+        if (structured) mine = !(wind_is_plain(P, PM_FMA(W.u, W.u, W.v * W.v), W.qU2r) && yj <= P.ymax);
         if (mine) {
             /* J[r][c] = d f_r / d u_c = dfs[c].r */
             Jm[0] = dfs[0].lne; Jm[1] = dfs[1].lne; Jm[2] = dfs[2].lne;

@@ -631,6 +631,7 @@ PX_EXPORT int32_t picles_create(const picles_grid *g, const picles_phys *p, cons
     P.propagation = p->propagation; P.input = p->input; P.dissipation = p->dissipation;
     P.peak_shift = p->peak_shift; P.direction = p->direction; P.n_is_2 = (P.n == 2.0);
     P.p_is_075 = (P.p == 0.75);
+    P.fast_phys = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
     P.abstol = o->abstol; P.reltol = o->reltol; P.dt0 = o->dt0; P.dtmin = o->dtmin;
     P.inv_abstol = 1.0 / o->abstol;
     P.maxiters = o->maxiters; P.force_dtmin = o->force_dtmin;

@@ -18,3 +18,17 @@ def test_device_math_equals_host_math_bitwise(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(" 0 mismatches") == 11, r.stdout
+
+
+@pytest.mark.gpu
+def test_structured_jacobian_device_equals_host_bitwise(tmp_path):
+    """physics.h rhs3_jac_plain (the Jacobian of the Rosenbrock23 attempt for a plain particle) and rhs3 on the device against the
+    same functions compiled for the host, entry by entry: ordinary seas and slow young seas just above the speed floor, with and
+    without the per-node metric term and the wind's slope (tests/native/gpu_jac_check.hip)"""
+    exe = tmp_path / "gpu_jac_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                    "-I", str(ROOT / "picles_amd" / "csrc"), str(ROOT / "tests" / "native" / "gpu_jac_check.hip"), "-o", str(exe)],
+                   check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" 0 mismatches") == 4, r.stdout
