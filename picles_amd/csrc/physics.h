@@ -6,16 +6,17 @@
  *   rhs               particle_system(dz,z,params,t), Cartesian mesh (particle_waves_v5.jl:479-556)
  *   integrate_dp5     step!(integrator, DT, true): DP5 / Tsit5 / AutoTsit5(Rosenbrock23()) + PI controller + Hairer
  *                     initial dt (call site mapping_2D.jl:152; OrdinaryDiffEq semantics: SURVEY Appendix C)
- *   rhs3_jvp, ros23_try   exact Jacobian of the RHS and the Rosenbrock23 attempt of the auto-switching solver
+ *   rhs3_jac_plain, rhs3_jvp, ros23_try   exact Jacobian of the RHS (structured / forward mode) and the Rosenbrock23 attempt of the auto-switching solver
  *   particle_to_charge / charge_to_particle   core_2D.jl:69-78 / :121-128
  *   index_weight      get_absolute_i_and_w(z, i_node)                 (ParticleInCell.jl:58-71)
  *
  * The evaluation order ("kernel order") is chosen for the CDNA4 fp64 VALU, where every instruction
- * costs one issue slot: 1/c_gp through a deterministic reciprocal square root (no sqrt, no division) feeds k_p, ω_p,
- * α², α_p and the direction term; |g| ≡ c_gp; sin 2(θ_c-θ_w) = 2·cross·dot/(U c_gp)²; H_β and Δ_β share one
- * reciprocal; the error norm takes one reciprocal and no square root; the tableau is read from LDS at the point of
- * use; every multiply-add that is fused is written as fma() and the TU is compiled with
- * -ffp-contract=off, so results are bit-identical to the CPU oracle built with the same
+ * costs one issue slot: y = 1/|c̄| through a deterministic reciprocal square root (no sqrt, no division) feeds k_p, ω_p,
+ * α², α_p and the direction term, the powers of r_g ride in constants; |g| ≡ c_gp; sin 2(θ_c-θ_w) = 2·cross·dot·y²/U²;
+ * the reference's guards (speed floors, the cap on α, zero tests) sit behind ONE wave-uniform test per evaluation ("plain"
+ * particles); H_β and Δ_β share one exponential and one reciprocal; the error norm takes one reciprocal and no square root;
+ * the tableau is read through scalar loads at the point of use; every multiply-add that is fused is written as fma() and
+ * the TU is compiled with -ffp-contract=off, so results are bit-identical to the CPU oracle built with the same
  * primitives (oracle order 1).  No MFMA: nothing here is a contraction.
  */
 #ifndef PICLES_PHYSICS_H
