@@ -55,15 +55,19 @@ def test_sphere_aqua_gpu_bitwise():
 
 
 @pytest.mark.gpu
-def test_sphere_unobserved_run_is_fused_and_bitwise():
+@pytest.mark.parametrize("solver", ["Tsit5", "AutoTsit5"])
+def test_sphere_unobserved_run_is_fused_and_bitwise(solver):
     """consecutive run!-style steps on the sphere with nobody reading State: one fused launch per step (k_step with
-    the per-node metric flavour); final State and particles equal the step-by-step oracle bitwise"""
+    the per-node metric flavour); final State and particles equal the step-by-step oracle bitwise.  With the default solver the
+    fused launch is the specialised auto-switching flavour while an observed step runs the general-physics stand-alone advance
+    (test_sphere_aqua_gpu_bitwise): both against the same oracle = the two paths take the same form of the Jacobian
+    (KParams::fast_phys)."""
     from picles_amd.simulations import Simulation, initialize_simulation
     from picles_amd.timesteppers import time_step
     from helpers import make_model
     def mk():
         c = configs.sphere_aqua(n_steps=8)
-        c.model["ODEsets"].solver = "Tsit5"        # the explicit pairs run fused; the default (auto-switching) solver does not
+        c.model["ODEsets"].solver = solver
         return c
     cfg = mk()
     g, o = make_model(mk(), "hip"), make_model(mk(), ("pmath", 1))
