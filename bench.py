@@ -454,14 +454,25 @@ def main():
                 m5, el5 = measure(None, None, 0.0, K5, W5, cfg=configs.growing_decaying_winds_lattice(n=2048, n_steps=K5 + W5 + 42))
                 r5 = summary(m5, el5, K5, W5)
                 del m5
-                bx = configs.box4096(n=2048)
-                bx.model["ODEsets"].solver = "AutoTsit5"
+                def bx2():
+                    b_ = configs.box4096(n=2048)
+                    b_.model["ODEsets"].solver = "AutoTsit5"
+                    return b_
+                bx = bx2()
                 mb, elb = measure(None, None, 0.0, 20, 5, cfg=bx)
                 rb = summary(mb, elb, 20, 5)
                 del mb
                 r5["workload"] = "cfg5: 2048x2048 non-periodic, winds ramp(x) x cos(3t/(3600 2pi)) as a device lattice (SMOOTH3, knots at dt/2), dt = 1200 s, AutoTsit5"
                 r5["homogeneous_box_2048_AutoTsit5"] = {k: rb[k] for k in ("ms_per_step", "rhs_per_s", "rhs_evals_per_particle_step", "lane_efficiency")}
                 r5["rhs_rate_over_homogeneous_box"] = r5["rhs_per_s"] / rb["rhs_per_s"]
+                # ... and the same box through config 5's own kernel flavour and wind path (its constant winds as a SMOOTH3 device lattice:
+                # three device-sampled levels per step, stage winds interpolated in time): "same solver and kernel flavour" 
+                bl = configs.closure_lattice(bx2(), 20 + 5 + 2, x=[0.0, 2000.0 * 2047], y=[0.0, 2000.0 * 2047])
+                ml, ell = measure(None, None, 0.0, 20, 5, cfg=bl)
+                rl = summary(ml, ell, 20, 5)
+                del ml
+                r5["homogeneous_box_2048_same_flavour"] = {k: rl[k] for k in ("ms_per_step", "rhs_per_s", "rhs_evals_per_particle_step", "lane_efficiency")}
+                r5["rhs_rate_over_same_flavour_box"] = r5["rhs_per_s"] / rl["rhs_per_s"]
                 return r5
 
             def reach2():

@@ -73,6 +73,8 @@ def _check_round4_legs(d):
         assert v["ms_per_step"] > 0 and v["halo_overflow"] == 0
     c5 = legs["cfg5_conformant_device_lattice"]
     assert "SMOOTH3" in c5["workload"] and 0 < c5["lane_efficiency"] <= 1 and c5["max_reach"] >= 2 and 0 < c5["rhs_rate_over_homogeneous_box"] < 1.5
+    if "rhs_rate_over_same_flavour_box" in c5:          # (from the end of round 4 on)
+        assert 0 < c5["rhs_rate_over_homogeneous_box"] <= c5["rhs_rate_over_same_flavour_box"] < 1.5
     assert legs["box_reach2"]["max_reach"] == 2
     assert legs["slab_4096x512_ring_of_one"]["slab_phases"]["steps"] == d["steps"]
 
