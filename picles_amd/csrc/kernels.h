@@ -416,7 +416,7 @@ __device__ __forceinline__ bool rows_index(const GridP &G, int r0, int n0, int r
      * every wave's chain of dependent prologue loads — the phase clock put that chain at a third of a wave's life) */
     /* One contiguous row range of whole 64-column strips, four rows at a time: the block is 64 columns x 4 rows, one wave per row,
      * instead of 256 consecutive nodes of one row.  A workgroup hands its wave slots on when the LAST of its four waves is done; four
-     * vertically adjacent 64-node pieces meet about the same wind and sea where a quarter-kilometre strip along a row does not (the
+     * vertically adjacent 64-node pieces meet about the same wind and sea where a 256-node strip along a row does not (the
      * wind ramp of BASELINE config 5: the waves of a strip took 30 to 57 µs and the launch ran 2.4 of 3 slots per SIMD filled).
      * Same number of blocks, same particles, each exactly once; the block number stays a label (XCD bands, cost-ordered dispatch). */
     if (n1 == 0 && (G.Nx & 63) == 0 && (n0 & 3) == 0) {

@@ -116,8 +116,9 @@ __device__ __forceinline__ double pm_sci_(void)
 
 /* A constant kept in a VECTOR register pair: an instruction reads at most one scalar operand, so of the two constants of
  * fma(x, 512/ln2, shifter) one has to be a vector register; left to itself the compiler re-creates it at some of its uses (s_mov,
- * s_mov, v_mov_b64: one issue slot each time).  Behind a side-effect-free asm the value is an ordinary loop-invariant: created once,
- * shared by every use (the asm statements are identical and merge).  Identity on the host. */
+ * s_mov, v_mov_b64: one issue slot each time).  Behind an asm the value is opaque — an ordinary loop invariant of the code that
+ * follows — but every pm_vc() is a value of its own: the Runge-Kutta loop creates ONE (PM_EXP_SHIFTER(), ahead of the loop) and hands
+ * it to all its exponentials.  Identity on the host. */
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double pm_vc(double c)
 {
@@ -217,9 +218,9 @@ __device__ __forceinline__ void pm_device_init(void) {}   /* host pass of hipcc:
  * x = (512 m + j) ln2/512 + r, |r| <= ln2/1024; exp(x) = 2^m * 2^(j/512) * (1 + r P3(r)); the truncation error
  * r^5/120 <= 1.2e-18 is far below the rounding of the final product. */
 /* expm1(r) = r + r² (1/2 + r/6 + r²/24) for |r| <= ln2/1024, in Estrin's form: four issue slots like Horner's, but every
- * instruction has at most ONE constant that is not an inline operand — on the device it rides in scalar registers (pm_sc), where
+ * instruction has at most ONE constant that is not an inline operand — on the device it rides in a scalar register pair, where
  * Horner's first step fma(1/24, r, 1/6) wants one of its two in a vector register pair (kept for the whole kernel, or copied at
- * every use) — and the dependent chain is one step shorter */
+ * every use: measured, one v_mov_b64 per exponential) — and the dependent chain is one step shorter */
 PM_HD double pm_expm1_poly(double r)
 {
     const double r2 = r * r;
