@@ -186,7 +186,10 @@ def _settle_rocm_runtime():
     runtime) and imports torch afterwards ends up with a mix of system and bundled libraries — it computes correctly and
     then aborts at exit (glibc "double free or corruption", seen on the MI355X boxes in round 2).  The multi-GPU driver and
     the tests do import torch, so: if torch is installed it is imported before the library is opened.  A host that never
-    touches torch can opt out with PICLES_NO_TORCH_PRELOAD=1."""
+    touches torch can opt out with PICLES_NO_TORCH_PRELOAD=1.
+    (Round 4 tried the lighter way — mapping the wheel's libamdhip64.so and librccl.so with RTLD_GLOBAL instead of importing torch, same
+    SONAME as the system's: the process still ended in "double free or corruption" when torch was imported later; more of the bundle
+    than those two has to come first.  The import stays.)"""
     import sys
     if "torch" in sys.modules or os.environ.get("PICLES_NO_TORCH_PRELOAD"):
         return
