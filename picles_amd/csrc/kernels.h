@@ -83,8 +83,15 @@ __device__ __forceinline__ int *reach_counters(const Arrays &A) { return (int *)
 #define PF_GROUP2 2
 #define PF_BOUNDARY 4
 
+/* sum over the 64 lanes of a wave (callers run with every lane active).  Where all lanes hold the same value — the statistics of a
+ * wave whose particles took the same number of attempts: every wave of a homogeneous sea — the sum is 64 times it: two lane reads,
+ * a compare and a scalar product instead of six rounds of cross-lane additions (~30 issue slots per sum, two sums per wave and step) */
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
+    const unsigned int lo0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+    const unsigned int hi0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
+    const unsigned long long v0 = ((unsigned long long)hi0 << 32) | lo0;
+    if (__all(v == v0)) return v0 * 64ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
