@@ -152,11 +152,18 @@ int32_t picles_set_winds3(picles_ctx *ctx, const double *u0, const double *v0, d
  * (t0,u0)-(tk,uk)-(t1,u1).  This is the exact form, inside one model step, of wind_interpolator's
  * linear_interpolation((x,y,t), u) (Utils/WindEmulator.jl:18-43) when one time knot of the lattice falls inside the step: the
  * reference's RHS evaluates that interpolant at every stage time (particle_waves_v5.jl:494-495), so the solver sees the kink.
- * A window without an interior knot is picles_set_winds; one with two or more is not representable (take model steps no longer
- * than the lattice's time spacing). */
+ * A window without an interior knot is picles_set_winds; one with two or more is picles_set_winds_polyline. */
 int32_t picles_set_winds_knot(picles_ctx *ctx, const double *u0, const double *v0, double t0,
                               const double *uk, const double *vk, double tk,
                               const double *u1, const double *v1, double t1);
+/* The general form: nlev >= 2 node-sampled levels (u[k], v[k]) at strictly increasing times[k], times[0] and times[nlev-1] the
+ * ends of the window — the piecewise-linear wind through them, i.e. the reference's interpolant inside a model step that holds
+ * nlev - 2 time knots of the wind lattice.  2 levels = picles_set_winds, 3 = picles_set_winds_knot; more: a POLYLINE window,
+ * u(s) = u0 + s du + Σ_k max(s - s_k, 0) b_k with one term per knot (at most PICLES_MAX_KNOTS = 8 knots).  A step under a polyline
+ * window runs the plain phases (stand-alone advance, general flavour; scatter + remesh behind it) instead of the fused launch —
+ * the same results to the bit, one launch more per step. */
+#define PICLES_MAX_KNOTS 8
+int32_t picles_set_winds_polyline(picles_ctx *ctx, int32_t nlev, const double *const *u, const double *const *v, const double *times);
 
 /* Non-Cartesian meshes (SphericalGrid.jl:207-240, spherical_grid_corrections.jl:3-21): per-node
  * projection kernel M = diag(m11, m22) of the propagation terms (particle_waves_v5.jl:536) and the
@@ -173,8 +180,10 @@ int32_t picles_set_metric(picles_ctx *ctx, const double *m11, const double *m22,
  * Time semantics inside a model step [t, t+Δt] (picles_set_wind_grid_mode; LINEAR after every picles_set_wind_grid):
  *   PICLES_LATTICE_LINEAR  the reference's: the interpolant itself, kinks included.  No lattice knot strictly inside the step:
  *                          two levels (t, t+Δt), a straight line.  One knot inside: a third level AT the knot, two straight
- *                          segments (= picles_set_winds_knot).  Two or more knots inside one step: the step is REFUSED with an
- *                          error text (take Δt <= the lattice's time spacing, or the mode below).
+ *                          segments (= picles_set_winds_knot).  Two to PICLES_MAX_KNOTS knots inside one step: a level at every
+ *                          knot, the polyline through them (= picles_set_winds_polyline; such a step takes the plain phases instead
+ *                          of the fused launch).  More than PICLES_MAX_KNOTS: the step is REFUSED with an error text before it has
+ *                          changed anything (take shorter steps, or the mode below).
  *   PICLES_LATTICE_SMOOTH3 for a lattice that tabulates a smooth closure u(x,y,t) (knots at Δt/2 or finer): three levels
  *                          (t, t+Δt/2, t+Δt), the parabola through them (= picles_set_winds3 with the lattice sampled on the
  *                          device) — what carries tests/T04_2D_reg_test.jl:166-167's cos(3t/(3600 2π)) forcing to 1e-3 with no
@@ -191,6 +200,9 @@ int32_t picles_set_wind_grid_mode(picles_ctx *ctx, int32_t mode);
  * from host-sampled levels (picles_set_winds_knot).  (The periodic continuation in t has a whole number of
  * lattice intervals as its period: knots stay at whole multiples of lat_dt from lat_t0.) */
 int32_t picles_lattice_knots(double lat_t0, double lat_dt, double t, double dt, double *tk);
+/* All of them: returns the number of lattice time knots strictly inside (t, t+dt) by the same rule and writes the times of the first
+ * `cap` into tks (tks may be NULL with cap = 0). */
+int32_t picles_lattice_knot_times(double lat_t0, double lat_dt, double t, double dt, double *tks, int32_t cap);
 /* node winds currently on the device (own rows); any pointer may be NULL */
 int32_t picles_get_winds(picles_ctx *ctx, double *u0, double *v0, double *u1, double *v1);
 /* the mid-window level of three-level winds; returns 1 (and writes nothing) when the current winds have two levels */

@@ -111,6 +111,7 @@ typedef struct po_consts {
     double p, n, e_T, inv_eT, inv_rg, inv_dx, inv_dy;
 } po_consts;
 
+#define PO_MAX_KNOTS 8      /* the product's PICLES_MAX_KNOTS */
 typedef struct po_model {
     picles_grid g;
     picles_phys ph;
@@ -145,6 +146,13 @@ typedef struct po_model {
     int wind_static;
     int wind_knot;             /* three levels, the middle one at the knot twk of a gridded wind (picles_oracle_set_winds_knot): two straight segments */
     double twk;
+    /* a polyline window (picles_oracle_set_winds_polyline): wind_nk >= 2 knots at ptk[0 .. nk) inside (tw0, tw1), the levels there in
+     * plu[k] / plv[k]; order 1 also keeps what the product's k_wind_poly lays down: the knots' s, the first segment's slope and the
+     * jumps of the slope at the knots (pcu[0] = du, pcu[k] = b_k) */
+    int wind_nk;
+    double ptk[PO_MAX_KNOTS], psk[PO_MAX_KNOTS];
+    double *plu[PO_MAX_KNOTS], *plv[PO_MAX_KNOTS];
+    double *pcu[PO_MAX_KNOTS + 1], *pcv[PO_MAX_KNOTS + 1];
     double clock;
     picles_counters cnt;
     char err[256];
@@ -448,6 +456,34 @@ static inline void po_wind(const po_model *M, int64_t idx, double t, double *u, 
         *v = M->v0[idx];
         return;
     }
+    if (M->wind_nk > 1) {
+        if (M->order == 0) {
+            /* several time knots inside the step: the lerp of the segment t falls into (Utils/WindEmulator.jl:18-43) */
+            const int nk = M->wind_nk;
+            int j = 0;
+            while (j < nk && t >= M->ptk[j]) j++;                 /* segment j: [T_j, T_j+1), T_0 = tw0, T_k = ptk[k-1], T_nk+1 = tw1 */
+            const double ta = j ? M->ptk[j - 1] : M->tw0, tb = (j < nk) ? M->ptk[j] : M->tw1;
+            const double ua = j ? M->plu[j - 1][idx] : M->u0[idx], ub = (j < nk) ? M->plu[j][idx] : M->u1[idx];
+            const double va = j ? M->plv[j - 1][idx] : M->v0[idx], vb = (j < nk) ? M->plv[j][idx] : M->v1[idx];
+            const double f = (t - ta) / (tb - ta);
+            *u = ua + (ub - ua) * f;
+            *v = va + (vb - va) * f;
+        } else {
+            /* kernel order (physics.h, wind_eval<true>): u0 + s du + Σ_k max(s - s_k, 0) b_k in the order of the knots */
+            const double idt = 1.0 / (M->tw1 - M->tw0);
+            const double s = (t - M->tw0) * idt;
+            double uu = PO_FMA(M->pcu[0][idx], s, M->u0[idx]), vv = PO_FMA(M->pcv[0][idx], s, M->v0[idx]);
+            for (int k = 0; k < M->wind_nk; k++) {
+                double sp = s - M->psk[k];
+                sp = (sp > 0.0) ? sp : 0.0;
+                uu = PO_FMA(M->pcu[k + 1][idx], sp, uu);
+                vv = PO_FMA(M->pcv[k + 1][idx], sp, vv);
+            }
+            *u = uu;
+            *v = vv;
+        }
+        return;
+    }
     if (M->order == 0) {
         if (M->um && M->wind_knot) {
             /* a gridded wind with one of its time knots inside the step (Utils/WindEmulator.jl:18-43: linear_interpolation in t,
@@ -505,6 +541,28 @@ static inline void po_wind_dt(const po_model *M, int64_t idx, double t, double *
     *dudt = *dvdt = 0.0;
     if (M->wind_static) return;
     const double idt = 1.0 / (M->tw1 - M->tw0);
+    if (M->wind_nk > 1) {
+        const int nk = M->wind_nk;
+        if (M->order == 0) {
+            int j = 0;
+            while (j < nk && t >= M->ptk[j]) j++;
+            const double ta = j ? M->ptk[j - 1] : M->tw0, tb = (j < nk) ? M->ptk[j] : M->tw1;
+            const double ua = j ? M->plu[j - 1][idx] : M->u0[idx], ub = (j < nk) ? M->plu[j][idx] : M->u1[idx];
+            const double va = j ? M->plv[j - 1][idx] : M->v0[idx], vb = (j < nk) ? M->plv[j][idx] : M->v1[idx];
+            *dudt = (ub - ua) / (tb - ta);
+            *dvdt = (vb - va) / (tb - ta);
+            return;
+        }
+        const double s = (t - M->tw0) * idt;
+        double su = M->pcu[0][idx], sv = M->pcv[0][idx];
+        su = (s >= M->psk[0]) ? su + M->pcu[1][idx] : su;
+        sv = (s >= M->psk[0]) ? sv + M->pcv[1][idx] : sv;
+        for (int k = 1; k < nk; k++)
+            if (s >= M->psk[k]) { su = su + M->pcu[k + 1][idx]; sv = sv + M->pcv[k + 1][idx]; }
+        *dudt = su * idt;
+        *dvdt = sv * idt;
+        return;
+    }
     if (M->um && M->wind_knot) {
         if (M->order == 0) {
             if (t < M->twk) {
@@ -1550,11 +1608,13 @@ PO_EXPORT int32_t picles_oracle_create(const picles_grid *g, const picles_phys *
     return 0;
 }
 
+static void po_polyline_free(po_model *M);
 PO_EXPORT int32_t picles_oracle_destroy(po_model *M)
 {
     if (!M) return 0;
     free(M->mask); free(M->state); free(M->movie); free(M->z); free(M->qold); free(M->asw); free(M->dtn); free(M->grp); free(M->rec);
     free(M->on); free(M->bnd); free(M->status); free(M->steplist);
+    po_polyline_free(M);
     free(M->u0); free(M->v0); free(M->u1); free(M->v1); free(M->um); free(M->vm);
     free(M->m11); free(M->m22); free(M->pc);
     free(M);
@@ -1577,6 +1637,13 @@ PO_EXPORT int32_t picles_oracle_set_metric(po_model *M, const double *m11, const
 
 PO_EXPORT int32_t picles_oracle_set_threads(po_model *M, int32_t n) { M->nthreads = n > 0 ? n : 1; return 0; }
 
+static void po_polyline_free(po_model *M)
+{
+    for (int k = 0; k < PO_MAX_KNOTS; k++) { free(M->plu[k]); free(M->plv[k]); M->plu[k] = M->plv[k] = NULL; }
+    for (int k = 0; k <= PO_MAX_KNOTS; k++) { free(M->pcu[k]); free(M->pcv[k]); M->pcu[k] = M->pcv[k] = NULL; }
+    M->wind_nk = 0;
+}
+
 PO_EXPORT int32_t picles_oracle_set_winds3(po_model *M, const double *u0, const double *v0, double t0,
                                            const double *um, const double *vm,
                                            const double *u1, const double *v1, double t1)
@@ -1585,6 +1652,7 @@ PO_EXPORT int32_t picles_oracle_set_winds3(po_model *M, const double *u0, const 
     memcpy(M->v0, v0, M->N * 8);
     M->tw0 = t0;
     M->wind_knot = 0;
+    po_polyline_free(M);
     free(M->um); free(M->vm);
     M->um = M->vm = NULL;
     if (u1 && v1 && t1 != t0) {
@@ -1618,6 +1686,48 @@ PO_EXPORT int32_t picles_oracle_set_winds(po_model *M, const double *u0, const d
                                           const double *u1, const double *v1, double t1)
 {
     return picles_oracle_set_winds3(M, u0, v0, t0, NULL, NULL, u1, v1, t1);
+}
+/* nlev >= 2 levels at strictly increasing times (the product's picles_set_winds_polyline): the reference's interpolant inside a step
+ * that holds nlev - 2 time knots of the wind lattice */
+PO_EXPORT int32_t picles_oracle_set_winds_polyline(po_model *M, int32_t nlev, const double *const *u, const double *const *v, const double *times)
+{
+    if (nlev < 2 || !u || !v || !times) return -2;
+    for (int k = 1; k < nlev; k++) if (!(times[k - 1] < times[k])) return -2;
+    if (nlev == 2) return picles_oracle_set_winds3(M, u[0], v[0], times[0], NULL, NULL, u[1], v[1], times[1]);
+    if (nlev == 3) return picles_oracle_set_winds_knot(M, u[0], v[0], times[0], u[1], v[1], times[1], u[2], v[2], times[2]);
+    const int nk = nlev - 2;
+    if (nk > PO_MAX_KNOTS) return -2;
+    int32_t rc = picles_oracle_set_winds_knot(M, u[0], v[0], times[0], u[1], v[1], times[1], u[nlev - 1], v[nlev - 1], times[nlev - 1]);
+    if (rc) return rc;
+    M->wind_nk = nk;
+    for (int k = 0; k < nk; k++) {
+        M->ptk[k] = times[k + 1];
+        M->plu[k] = (double *)malloc(M->N * 8); memcpy(M->plu[k], u[k + 1], M->N * 8);
+        M->plv[k] = (double *)malloc(M->N * 8); memcpy(M->plv[k], v[k + 1], M->N * 8);
+    }
+    /* what k_wind_poly lays down (picles_hip.hip): s of the knots, slopes per unit s of the segments, their jumps at the knots */
+    const double idt = 1.0 / (M->tw1 - M->tw0);
+    double ilen[PO_MAX_KNOTS + 1], sprev = 0.0;
+    for (int k = 0; k <= nk; k++) {
+        const double sn = (k < nk) ? (M->ptk[k] - M->tw0) * idt : 1.0;
+        if (k < nk) M->psk[k] = sn;
+        ilen[k] = 1.0 / (sn - sprev);
+        sprev = sn;
+    }
+    for (int k = 0; k <= nk; k++) { M->pcu[k] = (double *)malloc(M->N * 8); M->pcv[k] = (double *)malloc(M->N * 8); }
+    for (int64_t t = 0; t < M->N; t++) {
+        for (int c = 0; c < 2; c++) {
+            double prev = c ? M->v0[t] : M->u0[t], slp = 0.0;
+            for (int j = 0; j <= nk; j++) {
+                const double next = (j < nk) ? (c ? M->plv[j][t] : M->plu[j][t]) : (c ? M->v1[t] : M->u1[t]);
+                const double sl = (next - prev) * ilen[j];
+                (c ? M->pcv[j] : M->pcu[j])[t] = j ? sl - slp : sl;
+                slp = sl;
+                prev = next;
+            }
+        }
+    }
+    return 0;
 }
 
 /* init_particles! (run.jl:199-247) -> SeedParticle (core_2D.jl:434-488) -> InitParticleValues

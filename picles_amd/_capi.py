@@ -121,12 +121,14 @@ SYMBOLS = {
     "picles_set_winds3": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double]),
     "picles_set_winds_knot": (C.c_int32, [_VP, c_double_p, c_double_p, C.c_double, c_double_p, c_double_p, C.c_double,
                                           c_double_p, c_double_p, C.c_double]),
+    "picles_set_winds_polyline": (C.c_int32, [_VP, C.c_int32, C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p]),
     "picles_get_winds_mid": (C.c_int32, [_VP, c_double_p, c_double_p]),
     "picles_set_metric": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p]),
     "picles_set_wind_grid": (C.c_int32, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                          C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, C.c_double, C.c_double]),
     "picles_set_wind_grid_mode": (C.c_int32, [_VP, C.c_int32]),
     "picles_lattice_knots": (C.c_int32, [C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]),
+    "picles_lattice_knot_times": (C.c_int32, [C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, C.c_int32]),
     "picles_get_winds": (C.c_int32, [_VP, c_double_p, c_double_p, c_double_p, c_double_p]),
     "picles_seed": (C.c_int32, [_VP, C.c_double]),
     "picles_time_step": (C.c_int32, [_VP, C.c_double, C.c_int32]),

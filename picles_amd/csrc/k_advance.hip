@@ -43,13 +43,14 @@ __global__ void __launch_bounds__(256, (FAST && !AUTO) ? 4 : 2) k_advance(KParam
         z.lne = A.z[t]; z.cx = A.z[t + A.n]; z.cy = A.z[t + 2 * A.n]; z.x = A.z[t + 3 * A.n]; z.y = A.z[t + 4 * A.n];
         int on = A.on[t];
         double qold = A.qold[t], dtn = A.dtn[t];
-        Wind w = load_wind(P, A, t);
+        constexpr bool POLY = !FAST && !STATIC;      /* the general time-varying flavours carry polyline windows (physics.h, wind_eval) */
+        Wind w = load_wind<POLY>(P, A, t);
         int status;
         int asw = AUTO ? A.asw[t] : 0;
         /* behind the RK loop: guards, particle store, scatter record */
         auto finish = [&](const KParams &Pq, const GridP &Gq, const Arrays &Aq, long long tq, int iq, int jlq, unsigned char pfq,
                           double ts, double dt_step, int status) {
-            status = advance_guards(Pq, [&]() { return load_wind(Pq, Aq, tq); }, z, dtn, ts, dt_step, status, S);
+            status = advance_guards<POLY>(Pq, [&]() { return load_wind<POLY>(Pq, Aq, tq); }, z, dtn, ts, dt_step, status, S);
             if (AUTO) Aq.asw[tq] = asw;
             Aq.z[tq] = z.lne; Aq.z[tq + Aq.n] = z.cx; Aq.z[tq + 2 * Aq.n] = z.cy; Aq.z[tq + 3 * Aq.n] = z.x; Aq.z[tq + 4 * Aq.n] = z.y;
             Aq.on[tq] = (unsigned char)on;

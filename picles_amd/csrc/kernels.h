@@ -106,6 +106,9 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return v;
 }
 
+/* POLY: the caller can meet a polyline window (KParams::wind_nk >= 2; physics.h, wind_eval): the first segment's slope and the first
+ * knot's jump come from the planes k_wind_poly laid down */
+template <bool POLY = false>
 __device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, long long t)
 {
     Wind w;
@@ -113,6 +116,12 @@ __device__ __forceinline__ Wind load_wind(const KParams &P, const Arrays &A, lon
     w.v0 = A.v0[t];
     w.bu = 0.0;
     w.bv = 0.0;
+    w.xi = (unsigned int)t;
+    if (POLY && !P.wind_static && P.wind_nk > 1) {
+        const double *pl = P.wind_xb + PICLES_MAX_KNOTS + t;
+        w.du = pl[0]; w.dv = pl[P.wind_xn]; w.bu = pl[2 * P.wind_xn]; w.bv = pl[3 * P.wind_xn];
+        return w;
+    }
     if (P.wind_static) {
         w.du = 0.0;
         w.dv = 0.0;
@@ -190,7 +199,7 @@ __device__ __forceinline__ int advance_core(const KParams &P, const Wind &w, Vec
         status |= S.st.status;
     } else {
         double u, v;
-        wind_at(P, w, t_start + DT, u, v);
+        wind_at<(!FAST && !STATIC)>(P, w, t_start + DT, u, v);
         if (u * u + v * v >= P.wind_min_sq) {
             reseed(P, u, v, DT, z);
             dtn = -1.0;
@@ -203,21 +212,21 @@ __device__ __forceinline__ int advance_core(const KParams &P, const Wind &w, Vec
 
 /* WF: () -> Wind.  k_step hands in a loader instead of the wind itself: the node wind is needed behind the RK loop only by the
  * (rare) re-seeding guards, and kept in registers across the loop it is what the 128-register build spilled to scratch */
-template <class WF>
+template <bool POLY = false, class WF>
 __device__ __forceinline__ int advance_guards(const KParams &P, WF wind, Vec5 &z, double &dtn, double t_start, double DT,
                                               int status, StepStats &S)
 {
     if (pm_isnan(z.lne) || pm_isnan(z.cx) || pm_isnan(z.cy)) {
         double u, v;
         const Wind w = wind();
-        wind_at(P, w, t_start + DT, u, v);
+        wind_at<POLY>(P, w, t_start + DT, u, v);
         reseed(P, u, v, DT, z);
         dtn = -1.0;
         status |= PICLES_ST_RESEED_NAN;
     } else if (pm_isinf(z.lne) || pm_isinf(z.cx) || pm_isinf(z.cy)) {
         double u, v;
         const Wind w = wind();
-        wind_at(P, w, t_start, u, v);
+        wind_at<POLY>(P, w, t_start, u, v);
         reseed(P, u, v, DT, z);
         dtn = -1.0;
         status |= PICLES_ST_RESEED_INF;
@@ -446,7 +455,7 @@ __device__ __forceinline__ int remesh_regs(const KParams &P, const Wind &w, unsi
                                            double my, double clock, double DT, Vec5 &z)
 {
     double u, v;
-    wind_at(P, w, clock, u, v);          /* winds at model.clock.time, before tick! */
+    wind_at<true>(P, w, clock, u, v);    /* winds at model.clock.time, before tick!  (the stand-alone remesh: any window) */
     bool bnd = (pf & PF_BOUNDARY) != 0;
     if (!bnd && (e >= P.min_e) && (mx * mx + my * my >= P.min_m2)) {
         charge_to_particle(e, mx, my, z);
@@ -480,7 +489,7 @@ __device__ __forceinline__ void remesh_particle(const KParams &P, const Arrays &
                                                 double e, double mx, double my, double clock, double DT,
                                                 unsigned int &reseeds)
 {
-    Wind w = load_wind(P, A, t);
+    Wind w = load_wind<true>(P, A, t);
     Vec5 z;
     int br = remesh_regs(P, w, pf, e, mx, my, clock, DT, z);
     if (br <= 1) {

@@ -68,7 +68,17 @@ struct KParams {
      * smooth closure; 0 < wind_sk < 1: the piecewise-linear function with ONE knot at s = wind_sk — the exact form of a gridded wind
      * (Utils/WindEmulator.jl:18-43, linear_interpolation in t) one of whose time knots falls inside the model step */
     double wind_sk, wind_isk, wind_i1sk;   /* s of the knot, 1/sk, 1/(1 - sk) */
+    /* a window with TWO OR MORE knots inside the step (wind_nk >= 2): the polyline  u(s) = u0 + s du + Σ_k max(s - s_k, 0) b_k  with
+     * one term per knot.  Its coefficients are laid down once per step by k_wind_poly (picles_hip.hip) in wind_xb:
+     * [0 .. PICLES_MAX_KNOTS) the s_k, then planes of wind_xn doubles: du, dv, b_1u, b_1v, b_2u, b_2v, ...  Only the general
+     * flavours of the stand-alone phases carry such a window (wind_eval<true>); the fused step never meets one (step_fusable). */
+    int wind_nk, wind_pad_;
+    const double *wind_xb;
+    long long wind_xn;
 };
+#ifndef PICLES_MAX_KNOTS
+#define PICLES_MAX_KNOTS 8
+#endif
 
 /* Dormand–Prince 5(4) */
 #define DP_A21 (1.0 / 5.0)
@@ -242,6 +252,7 @@ struct Vec5 {
 struct Wind {
     double u0, v0, du, dv; /* level 0 and (level1 - level0) [knot form: the first segment's slope per unit s] */
     double bu, bv;         /* curvature term of the three-level window (0: linear in t) [knot form: the slope's jump at the knot] */
+    unsigned int xi;       /* the node (polyline windows read the terms of their further knots from wind_xb; dead in every other flavour) */
 };
 /* The parabola keeps the arithmetic of the two- and three-level windows of rounds 1-3, u0 + s (du + (s - 1) bu); the knot form sits
  * behind ONE kernel-uniform (scalar) branch per evaluation that covers both components.  Measured on MI355X, default-solver flavour,
@@ -266,6 +277,42 @@ PM_HD double wind_slope(const KParams &P, double du, double bu, double s)
 {
     if (P.wind_sk > 0.0) return (s >= P.wind_sk) ? du + bu : du;
     return PM_FMA(bu, PM_FMA(2.0, s, -1.0), du);
+}
+/* The polyline (KParams::wind_nk >= 2): a gridded wind with several of its time knots inside the model step — the reference's
+ * linear_interpolation((x,y,t), u) (Utils/WindEmulator.jl:18-43) is piecewise linear in t with a kink at every one of them.  The knot
+ * form with one more term per further knot, summed in the order of the knots; w.du, w.bu hold the first segment's slope and the first
+ * knot's jump, the jumps of the further knots are read from wind_xb when they are needed (a rare window: nothing is kept in
+ * registers for it).  POLY == false compiles to wind_eval2: the fused kernels and the specialised flavours do not carry the branch. */
+template <bool POLY>
+PM_HD void wind_eval(const KParams &P, const Wind &w, double s, double &u, double &v)
+{
+    if (POLY && P.wind_nk > 1) {
+        const double *xb = P.wind_xb;
+        double sp = s - xb[0];
+        sp = (sp > 0.0) ? sp : 0.0;
+        u = PM_FMA(w.bu, sp, PM_FMA(w.du, s, w.u0));
+        v = PM_FMA(w.bv, sp, PM_FMA(w.dv, s, w.v0));
+        for (int k = 1; k < P.wind_nk; k++) {
+            sp = s - xb[k];
+            sp = (sp > 0.0) ? sp : 0.0;
+            const double *pl = xb + PICLES_MAX_KNOTS + (long long)(2 * (k + 1)) * P.wind_xn + w.xi;
+            u = PM_FMA(pl[0], sp, u);
+            v = PM_FMA(pl[P.wind_xn], sp, v);
+        }
+        return;
+    }
+    wind_eval2(P, w, s, u, v);
+}
+/* d/ds of a polyline window, both components */
+PM_HD void wind_slopes_poly(const KParams &P, const Wind &w, double s, double &su, double &sv)
+{
+    const double *xb = P.wind_xb;
+    su = (s >= xb[0]) ? w.du + w.bu : w.du;
+    sv = (s >= xb[0]) ? w.dv + w.bv : w.dv;
+    for (int k = 1; k < P.wind_nk; k++) {
+        const double *pl = xb + PICLES_MAX_KNOTS + (long long)(2 * (k + 1)) * P.wind_xn + w.xi;
+        if (s >= xb[k]) { su = su + pl[0]; sv = sv + pl[P.wind_xn]; }
+    }
 }
 
 struct PStats {
@@ -295,6 +342,7 @@ PM_HD void wind_derive(const KParams &P, double u, double v, WindD &d)
 }
 /* the same for the stage winds of a time-varying window (seven times per RK attempt) */
 PM_HD void wind_derive_stage(const KParams &P, double u, double v, WindD &d) { wind_derive(P, u, v, d); }
+template <bool POLY = false>
 PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double &v)
 {
     if (P.wind_static) {
@@ -302,16 +350,16 @@ PM_HD void wind_at(const KParams &P, const Wind &w, double t, double &u, double 
         v = w.v0;
     } else {
         double s = (t - P.tw0) * P.inv_dtw;
-        wind_eval2(P, w, s, u, v);
+        wind_eval<POLY>(P, w, s, u, v);
     }
 }
-template <bool STATIC>
+template <bool STATIC, bool POLY = false>
 PM_HD void wind_stage(const KParams &P, const Wind &w, double t, WindD &d)
 {
     if (!STATIC) {
         double s = (t - P.tw0) * P.inv_dtw;
         double u, v;
-        wind_eval2(P, w, s, u, v);
+        wind_eval<POLY>(P, w, s, u, v);
         wind_derive_stage(P, u, v, d);
     }
 }
@@ -765,14 +813,22 @@ template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z, const Vec3 &f0, double t, double h,
                        double ipx, double ipy, double pc, Vec5 &un, Vec3 &f2, double &eig, PStats &st)
 {
+    constexpr bool POLY = !FAST && !STATIC;      /* the general time-varying flavours carry polyline windows (wind_eval) */
     const bool tv = !STATIC && !P.wind_static;   /* a time-varying instantiation may run with static winds: no dT terms then */
     double dudt = 0.0, dvdt = 0.0;
     if (!STATIC) {      /* du/dt, dv/dt of the window's interpolant at t: parabola (du + (2 s - 1) bu) / (tw1 - tw0); knot form: the segment's slope */
         const double s_ = (t - P.tw0) * P.inv_dtw;
-        dudt = wind_slope(P, w.du, w.bu, s_) * P.inv_dtw;
-        dvdt = wind_slope(P, w.dv, w.bv, s_) * P.inv_dtw;
+        if (POLY && P.wind_nk > 1) {
+            double su_, sv_;
+            wind_slopes_poly(P, w, s_, su_, sv_);
+            dudt = su_ * P.inv_dtw;
+            dvdt = sv_ * P.inv_dtw;
+        } else {
+            dudt = wind_slope(P, w.du, w.bu, s_) * P.inv_dtw;
+            dvdt = wind_slope(P, w.dv, w.bv, s_) * P.inv_dtw;
+        }
     }
-    wind_stage<STATIC>(P, w, t, W);
+    wind_stage<STATIC, POLY>(P, w, t, W);
     double Jm[9];
     Vec3 dT = {0.0, 0.0, 0.0};
     /* the specialised physics takes the structured Jacobian (rhs3_jac_plain); a lane whose particle is not plain — and every lane of
@@ -849,14 +905,14 @@ PM_HD double ros23_try(const KParams &P, const Wind &w, WindD &W, const Vec5 &z,
     const double h2 = 0.5 * h;
     const double sl = PM_FMA(h2, k1.lne, z.lne), sx = PM_FMA(h2, k1.cx, z.cx), sy = PM_FMA(h2, k1.cy, z.cy);
     Vec3 f1;
-    wind_stage<STATIC>(P, w, t + h2, W);
+    wind_stage<STATIC, POLY>(P, w, t + h2, W);
     rhs3<FAST, METRIC>(P, sl, sx, sy, W, f1, pc);
     const double f1x = sx * ipx, f1y = sy * ipy;
     WSOLVE(f1.lne - k1.lne, f1.cx - k1.cx, f1.cy - k1.cy, f1x - k1.x, f1y - k1.y, k2);
     k2.lne = k2.lne + k1.lne; k2.cx = k2.cx + k1.cx; k2.cy = k2.cy + k1.cy; k2.x = k2.x + k1.x; k2.y = k2.y + k1.y;
     un.lne = PM_FMA(h, k2.lne, z.lne); un.cx = PM_FMA(h, k2.cx, z.cx); un.cy = PM_FMA(h, k2.cy, z.cy);
     un.x = PM_FMA(h, k2.x, z.x); un.y = PM_FMA(h, k2.y, z.y);
-    wind_stage<STATIC>(P, w, t + h, W);
+    wind_stage<STATIC, POLY>(P, w, t + h, W);
     rhs3<FAST, METRIC>(P, un.lne, un.cx, un.cy, W, f2, pc);
     st.rhs += 2;
     const double f2x = un.cx * ipx, f2y = un.cy * ipy;
@@ -915,6 +971,7 @@ template <bool FAST, bool STATIC, bool METRIC>
 PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, const Vec3 &k1, double kx, double ky,
                      double ipx, double ipy, double pc, double t, PStats &st)
 {
+    constexpr bool POLY = !FAST && !STATIC;
     /* kernel order: 1/sk for (lne, c̄x, c̄y) from ONE reciprocal of the product of the three scales;
      * the RMS norms stay squared (S = d²): dt0 = 0.01 d0/d1 = 0.01 S0 / sqrt(S0 S1) through the
      * deterministic rsqrt, and the second-derivative estimate works on max(d1², d2²) with the coarse
@@ -939,7 +996,7 @@ PM_HD double init_dt(const KParams &P, const Wind &w, WindD &W, const Vec5 &u0, 
     if (dt0 < 10.0 * 2.220446049250313e-16) return 1e-6;
     double l1 = PM_FMA(dt0, k1.lne, u0.lne), cx1 = PM_FMA(dt0, k1.cx, u0.cx), cy1 = PM_FMA(dt0, k1.cy, u0.cy);
     Vec3 f1;
-    wind_stage<STATIC>(P, w, t + dt0, W);
+    wind_stage<STATIC, POLY>(P, w, t + dt0, W);
     rhs3<FAST, METRIC>(P, l1, cx1, cy1, W, f1, pc);
     st.rhs++;
     double f1x = cx1 * ipx, f1y = cy1 * ipy;
@@ -974,6 +1031,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     /* projection M = diag(ipx, ipy): 1/Δx, 1/Δy on the Cartesian mesh, per node otherwise */
     const double ipx = (FAST || P.propagation) ? (METRIC ? m11 : P.inv_dx) : 0.0;
     const double ipy = (FAST || P.propagation) ? (METRIC ? m22 : P.inv_dy) : 0.0;
+    constexpr bool POLY = !FAST && !STATIC;      /* the general time-varying flavours carry polyline windows (wind_eval) */
     Vec3 k1, k2, k3, k4, k5, k6, k7;
     WindD W;
     W.sh = PM_EXP_SHIFTER();
@@ -982,7 +1040,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
     constexpr double beta1 = TSIT ? PI_BETA1_TSIT : PI_BETA1, beta2 = TSIT ? PI_BETA2_TSIT : PI_BETA2;
     double tr = 0.0;
     if (STATIC) wind_derive(P, w.u0, w.v0, W);
-    else wind_stage<false>(P, w, t_start, W);
+    else wind_stage<false, POLY>(P, w, t_start, W);
     rhs3<FAST, METRIC>(P, z.lne, z.cx, z.cy, W, k1, pc);
     st.rhs++;
     double dt = dtn;
@@ -1035,7 +1093,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
             double a21h = h * TT(a21);
             gl = PM_FMA(a21h, k1.lne, z.lne); gx = PM_FMA(a21h, k1.cx, z.cx); gy = PM_FMA(a21h, k1.cy, z.cy);
         }
-        wind_stage<STATIC>(P, w, PM_FMA(TT(c2), h, t), W);
+        wind_stage<STATIC, POLY>(P, w, PM_FMA(TT(c2), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k2, pc);
         if (has2) {
             ax = PM_FMA(TT(a72), gx, ax); ay = PM_FMA(TT(a72), gy, ay);
@@ -1045,7 +1103,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #define ST3(c) PM_FMA(h, PM_FMA(TT(a32), k2.c, TT(a31) * k1.c), z.c)
         TT_STAGE();
         gl = ST3(lne); gx = ST3(cx); gy = ST3(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(TT(c3), h, t), W);
+        wind_stage<STATIC, POLY>(P, w, PM_FMA(TT(c3), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k3, pc);
         ax = PM_FMA(TT(a73), gx, ax); ay = PM_FMA(TT(a73), gy, ay);
         ex = PM_FMA(TT(e3), gx, ex); ey = PM_FMA(TT(e3), gy, ey);
@@ -1053,7 +1111,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #define ST4(c) PM_FMA(h, PM_FMA(TT(a43), k3.c, PM_FMA(TT(a42), k2.c, TT(a41) * k1.c)), z.c)
         TT_STAGE();
         gl = ST4(lne); gx = ST4(cx); gy = ST4(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(TT(c4), h, t), W);
+        wind_stage<STATIC, POLY>(P, w, PM_FMA(TT(c4), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k4, pc);
         ax = PM_FMA(TT(a74), gx, ax); ay = PM_FMA(TT(a74), gy, ay);
         ex = PM_FMA(TT(e4), gx, ex); ey = PM_FMA(TT(e4), gy, ey);
@@ -1061,7 +1119,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #define ST5(c) PM_FMA(h, PM_FMA(TT(a54), k4.c, PM_FMA(TT(a53), k3.c, PM_FMA(TT(a52), k2.c, TT(a51) * k1.c))), z.c)
         TT_STAGE();
         gl = ST5(lne); gx = ST5(cx); gy = ST5(cy);
-        wind_stage<STATIC>(P, w, PM_FMA(TT(c5), h, t), W);
+        wind_stage<STATIC, POLY>(P, w, PM_FMA(TT(c5), h, t), W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k5, pc);
         ax = PM_FMA(TT(a75), gx, ax); ay = PM_FMA(TT(a75), gy, ay);
         ex = PM_FMA(TT(e5), gx, ex); ey = PM_FMA(TT(e5), gy, ey);
@@ -1070,7 +1128,7 @@ PM_HD void integrate_dp5(const KParams &P, const Wind &w, Vec5 &z, double &lq, d
 #define ST6(c) PM_FMA(h, PM_FMA(TT(a65), k5.c, PM_FMA(TT(a64), k4.c, PM_FMA(TT(a63), k3.c, PM_FMA(TT(a62), k2.c, TT(a61) * k1.c)))), z.c)
         TT_STAGE();
         gl = ST6(lne); gx = ST6(cx); gy = ST6(cy);
-        wind_stage<STATIC>(P, w, t + h, W);
+        wind_stage<STATIC, POLY>(P, w, t + h, W);
         rhs3<FAST, METRIC>(P, gl, gx, gy, W, k6, pc);
         ax = PM_FMA(TT(a76), gx, ax); ay = PM_FMA(TT(a76), gy, ay);
         ex = PM_FMA(TT(e6), gx, ex); ey = PM_FMA(TT(e6), gy, ey);

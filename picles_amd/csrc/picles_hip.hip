@@ -67,9 +67,9 @@ __global__ void __launch_bounds__(256) k_seed(KParams P, GridP G, Arrays A, cons
     int on = 0;
     double e = 0.0, mx = 0.0, my = 0.0;
     if (mask[t] != 0) {
-        Wind w = load_wind(P, A, t);
+        Wind w = load_wind<true>(P, A, t);
         double u, v;
-        wind_at(P, w, 0.0, u, v);   /* winds at t = 0.0 (run.jl:213-215) */
+        wind_at<true>(P, w, 0.0, u, v);   /* winds at t = 0.0 (run.jl:213-215) */
         if (P.init_type == 0) {
             if (__builtin_sqrt(u * u + v * v) > __builtin_sqrt(2.0)) {
                 seed_windsea(u, v, seed_T, z.lne, z.cx, z.cy);
@@ -390,6 +390,32 @@ __global__ void __launch_bounds__(256) k_wind_sample(GridP G, WindGrid Wg, WindS
 }
 
 /* ------------------------------------------------------------------------------------------
+ * k_wind_poly — coefficients of a polyline window (KParams::wind_nk >= 2; physics.h, wind_eval): from the node's levels
+ * L_0 (u0 plane), L_1 .. L_nk (lv planes, one pair per knot), L_nk+1 (u1 plane) the segment slopes per unit s,
+ * sl_j = (L_j+1 - L_j) ilen_j, and their jumps at the knots:  du = sl_0,  b_k = sl_k - sl_k-1.  xb: [0, PICLES_MAX_KNOTS) the
+ * knots' s, then planes du, dv, b_1u, b_1v, b_2u, ...
+ * ---------------------------------------------------------------------------------------- */
+struct WindPolyForm { int nk; double sk[PICLES_MAX_KNOTS]; double ilen[PICLES_MAX_KNOTS + 1]; };
+__global__ void __launch_bounds__(256) k_wind_poly(WindPolyForm F, const double *u0, const double *v0, const double *u1, const double *v1,
+                                                   const double *lv, double *xb, long long n)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < PICLES_MAX_KNOTS) xb[t] = (t < F.nk) ? F.sk[t] : 2.0;    /* (beyond the window: never reached) */
+    if (t >= n) return;
+    double *pl = xb + PICLES_MAX_KNOTS;
+    for (int c = 0; c < 2; c++) {
+        double prev = c ? v0[t] : u0[t], slp = 0.0;
+        for (int j = 0; j <= F.nk; j++) {
+            const double next = (j < F.nk) ? lv[(size_t)(2 * j + c) * n + t] : (c ? v1[t] : u1[t]);
+            const double sl = (next - prev) * F.ilen[j];
+            pl[(size_t)(2 * j + c) * n + t] = j ? sl - slp : sl;
+            slp = sl;
+            prev = next;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * host side
  * ---------------------------------------------------------------------------------------- */
 static thread_local std::string g_create_error;
@@ -458,6 +484,8 @@ struct picles_ctx {
     bool ord_valid = false;        /* the previous fused step filed a dispatch order (kernels.h: Arrays::ord) with ... */
     int ord_nblk = 0;              /* ... this many workgroups: the whole grid, or the interior rows of a slab */
     double *um_buf = nullptr, *vm_buf = nullptr;   /* mid-window wind level (picles_set_winds3); A.um / A.vm point here while in use */
+    double *lv_buf = nullptr, *xb_buf = nullptr;   /* polyline windows: the levels at the knots (2 planes per knot) and the coefficient planes (k_wind_poly) */
+    int poly_cap = 0;                              /* knots the two buffers hold */
     bool ext_streams = false;      /* a caller-provided stream has been used: order across streams with device syncs */
     bool ring_orders = false;      /* inside picles_slab_run_steps: the ring orders its streams against the context stream with events */
     /* generic scatter scratch */
@@ -749,6 +777,7 @@ PX_EXPORT int32_t picles_destroy(picles_ctx *c)
     hipFree(A.pflags); hipFree(A.status); hipFree(A.u0); hipFree(A.v0); hipFree(A.u1); hipFree(A.v1);
     if (A.uP) { hipFree(A.uP); hipFree(A.vP); }
     if (c->um_buf) { hipFree(c->um_buf); hipFree(c->vm_buf); }
+    if (c->lv_buf) { hipFree(c->lv_buf); hipFree(c->xb_buf); }
     hipFree(A.cnt); hipFree(A.rmap); hipFree(c->d_mask);
     if (A.ord) hipFree(A.ord);
     if (A.m11) { hipFree(A.m11); hipFree(A.m22); hipFree(A.pc); }
@@ -785,6 +814,8 @@ PX_EXPORT int32_t picles_sync(picles_ctx *c)
 
 PX_EXPORT double picles_clock(const picles_ctx *c) { return c ? c->clock : 0.0; }
 
+static inline unsigned nblocks(long long n, int b) { return (unsigned)((n + b - 1) / b); }
+
 /* form of a three-level window: the parabola through (t0, (t0+t1)/2, t1), or two straight segments meeting at the knot tk */
 static void wind_window_form(picles_ctx *c, double t0, double t1, bool knot, double tk)
 {
@@ -798,6 +829,46 @@ static void wind_window_form(picles_ctx *c, double t0, double t1, bool knot, dou
     } else {
         P.wind_sk = P.wind_isk = P.wind_i1sk = 0.0;
     }
+    P.wind_nk = knot ? 1 : 0;
+}
+
+/* a polyline window over [t0, t1] with knots tk[0 .. nk) (nk >= 2): the levels at the knots are in lv_buf, levels 0 and nk+1 in the
+ * (u0, v0) / (u1, v1) planes; lays down the coefficient planes and sets the window's form.  (um, vm) = the first knot's level and the
+ * one-knot scalars describe the first knot: whatever evaluates the window at its START without knowing about polylines — the fused
+ * step's remesh reads level 0 from its plane — still gets level 0. */
+static int wind_poly_buffers(picles_ctx *c, int nk)
+{
+    if (nk <= c->poly_cap) return 0;
+    if (c->lv_buf) { hipFree(c->lv_buf); hipFree(c->xb_buf); c->lv_buf = c->xb_buf = nullptr; c->poly_cap = 0; }
+    const size_t n = (size_t)c->A.n;
+    HIPCHK(c, hipMalloc(&c->lv_buf, (size_t)2 * nk * n * 8));
+    HIPCHK(c, hipMalloc(&c->xb_buf, ((size_t)PICLES_MAX_KNOTS + (size_t)2 * (nk + 1) * n) * 8));
+    c->poly_cap = nk;
+    return 0;
+}
+static int wind_window_poly(picles_ctx *c, double t0, double t1, int nk, const double *tk, hipStream_t s)
+{
+    KParams &P = c->P;
+    Arrays &A = c->A;
+    wind_window_form(c, t0, t1, true, tk[0]);
+    WindPolyForm F;
+    F.nk = nk;
+    double sprev = 0.0;
+    for (int k = 0; k < PICLES_MAX_KNOTS; k++) F.sk[k] = 2.0;
+    for (int k = 0; k <= nk; k++) {
+        const double sn = (k < nk) ? (tk[k] - t0) * P.inv_dtw : 1.0;
+        if (k < nk) F.sk[k] = sn;
+        F.ilen[k] = 1.0 / (sn - sprev);
+        sprev = sn;
+    }
+    for (int k = nk + 1; k <= PICLES_MAX_KNOTS; k++) F.ilen[k] = 0.0;
+    hipLaunchKernelGGL(k_wind_poly, dim3(nblocks(A.n, 256)), dim3(256), 0, s, F, A.u0, A.v0, A.u1, A.v1, c->lv_buf, c->xb_buf, A.n);
+    HIPCHK(c, hipGetLastError());
+    A.um = c->lv_buf; A.vm = c->lv_buf + A.n;
+    P.wind_nk = nk;
+    P.wind_xb = c->xb_buf;
+    P.wind_xn = A.n;
+    return 0;
 }
 
 static int set_wind_levels(picles_ctx *c, const double *u0, const double *v0, double t0,
@@ -825,6 +896,7 @@ static int set_wind_levels(picles_ctx *c, const double *u0, const double *v0, do
         c->P.tw0 = t0;
         c->P.inv_dtw = 0.0;
         c->P.wind_sk = c->P.wind_isk = c->P.wind_i1sk = 0.0;
+        c->P.wind_nk = 0;
     }
     if (three) {                         /* third level: the planes exist from the first three-level call on */
         if (!c->um_buf) {
@@ -864,7 +936,37 @@ PX_EXPORT int32_t picles_set_winds_knot(picles_ctx *c, const double *u0, const d
     return set_wind_levels(c, u0, v0, t0, uk, vk, true, tk, u1, v1, t1);
 }
 
-static inline unsigned nblocks(long long n, int b) { return (unsigned)((n + b - 1) / b); }
+/* nlev >= 2 node-sampled levels at strictly increasing times: the piecewise-linear wind through them (a gridded wind sampled by the
+ * host at every time knot inside the step and at its ends).  2 levels = picles_set_winds, 3 = picles_set_winds_knot; more: the
+ * polyline window (at most PICLES_MAX_KNOTS levels between the ends). */
+PX_EXPORT int32_t picles_set_winds_polyline(picles_ctx *c, int32_t nlev, const double *const *u, const double *const *v, const double *times)
+{
+    if (!c) return -1;
+    if (nlev < 2 || !u || !v || !times) return fail(c, -2, "picles_set_winds_polyline needs at least two levels");
+    for (int k = 0; k < nlev; k++) if (!u[k] || !v[k]) return fail(c, -2, "picles_set_winds_polyline: a level is missing");
+    for (int k = 1; k < nlev; k++) if (!(times[k - 1] < times[k])) return fail(c, -2, "picles_set_winds_polyline: the level times must increase strictly");
+    if (nlev == 2) return set_wind_levels(c, u[0], v[0], times[0], nullptr, nullptr, false, 0.0, u[1], v[1], times[1]);
+    if (nlev == 3) return set_wind_levels(c, u[0], v[0], times[0], u[1], v[1], true, times[1], u[2], v[2], times[2]);
+    const int nk = nlev - 2;
+    if (nk > PICLES_MAX_KNOTS) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "picles_set_winds_polyline: %d levels inside the window, at most %d are carried", nk, PICLES_MAX_KNOTS);
+        return fail(c, -2, buf);
+    }
+    /* levels 0, 1 and the last through the three-level path (the one-knot form of the first knot), then the further knots */
+    int rc = set_wind_levels(c, u[0], v[0], times[0], u[1], v[1], true, times[1], u[nlev - 1], v[nlev - 1], times[nlev - 1]);
+    if (rc) return rc;
+    if ((rc = wind_poly_buffers(c, nk))) return rc;
+    const size_t b = (size_t)c->A.n * 8;
+    for (int k = 0; k < nk; k++) {
+        HIPCHK(c, hipMemcpyAsync(c->lv_buf + (size_t)(2 * k) * c->A.n, u[k + 1], b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->lv_buf + (size_t)(2 * k + 1) * c->A.n, v[k + 1], b, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = wind_window_poly(c, times[0], times[nlev - 1], nk, times + 1, c->stream))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));   /* caller may reuse its host buffers */
+    return 0;
+}
+
 
 /* per-node ProjetionKernel diagonal + PropagationCorrection coefficient */
 PX_EXPORT int32_t picles_set_metric(picles_ctx *c, const double *m11, const double *m22, const double *pc)
@@ -907,6 +1009,7 @@ PX_EXPORT int32_t picles_set_wind_grid(picles_ctx *c, int32_t nx, int32_t ny, in
     c->wg_t0 = t0; c->wg_dt = dt;
     c->A.um = c->A.vm = nullptr;
     c->P.wind_sk = c->P.wind_isk = c->P.wind_i1sk = 0.0;
+    c->P.wind_nk = 0;
     c->wind_grid_on = true;
     c->wind_grid_mode = PICLES_LATTICE_LINEAR;
     c->wind_t1_valid = false;
@@ -937,26 +1040,40 @@ PX_EXPORT int32_t picles_lattice_knots(double lat_t0, double lat_dt, double t, d
     return (k0 + 1.0 < c1 - eps) ? 2 : 1;
 }
 
-/* what the step window [t, t + dt] over the lattice looks like: levels, form, time of the middle level */
-struct WindowPlan { bool three; bool knot; double tm; };
+/* all of them: the number of time knots strictly inside (t, t + dt) (same rule), the first `cap` of their times in tks */
+PX_EXPORT int32_t picles_lattice_knot_times(double lat_t0, double lat_dt, double t, double dt, double *tks, int32_t cap)
+{
+    const double eps = 1e-9;
+    const double c0 = (t - lat_t0) / lat_dt, c1 = (t + dt - lat_t0) / lat_dt;
+    int n = 0;
+    for (double k = __builtin_floor(c0 + eps) + 1.0; k < c1 - eps; k += 1.0) {
+        if (tks && n < cap) tks[n] = lat_t0 + k * lat_dt;
+        if (++n == 0x7fffffff) break;
+    }
+    return n;
+}
+
+/* what the step window [t, t + dt] over the lattice looks like: levels, form, time of the middle level; nk >= 2: a polyline window
+ * with knots at tk[0 .. nk) */
+struct WindowPlan { bool three; bool knot; double tm; int nk; double tk[PICLES_MAX_KNOTS]; };
 static int wind_window_plan(picles_ctx *c, double t, double dt, WindowPlan &W)
 {
-    W = {false, false, 0.0};
+    W = WindowPlan{};
     if (c->wind_grid_mode == PICLES_LATTICE_SMOOTH3) {
         W.three = true;
         W.tm = t + 0.5 * dt;
         return 0;
     }
-    double tk = 0.0;
-    const int nk = picles_lattice_knots(c->wg_t0, c->wg_dt, t, dt, &tk);
-    if (nk >= 2) {
-        char buf[320];
-        snprintf(buf, sizeof buf, "the model step [%.17g, %.17g] contains two or more time knots of the wind lattice (spacing %.17g s): "
-                 "its piecewise-linear wind cannot be carried by one window — take model steps no longer than the lattice spacing, "
-                 "or picles_set_wind_grid_mode(PICLES_LATTICE_SMOOTH3) if the lattice tabulates a smooth closure", t, t + dt, c->wg_dt);
+    const int nk = picles_lattice_knot_times(c->wg_t0, c->wg_dt, t, dt, W.tk, PICLES_MAX_KNOTS);
+    if (nk > PICLES_MAX_KNOTS) {
+        char buf[360];
+        snprintf(buf, sizeof buf, "the model step [%.17g, %.17g] contains %d time knots of the wind lattice (spacing %.17g s); a window carries at most %d: "
+                 "take shorter model steps, or picles_set_wind_grid_mode(PICLES_LATTICE_SMOOTH3) if the lattice tabulates a smooth closure",
+                 t, t + dt, nk, c->wg_dt, PICLES_MAX_KNOTS);
         return fail(c, -7, buf);
     }
-    if (nk == 1) { W.three = true; W.knot = true; W.tm = tk; }
+    if (nk >= 1) { W.three = true; W.knot = true; W.tm = W.tk[0]; }
+    W.nk = nk;
     return 0;
 }
 
@@ -966,13 +1083,33 @@ static int wind_window_sample(picles_ctx *c, const WindowPlan &W, double t, doub
 {
     Arrays &A = c->A;
     dim3 grid(nblocks(A.n, 256)), block(256);
-    if (W.three && !c->um_buf) {
+    if (W.three && W.nk < 2 && !c->um_buf) {
         HIPCHK(c, hipMalloc(&c->um_buf, (size_t)A.n * 8));
         HIPCHK(c, hipMalloc(&c->vm_buf, (size_t)A.n * 8));
     }
     if (with0) {
         WindSampleOut O = {{t, 0.0}, {A.u0, nullptr}, {A.v0, nullptr}};
         hipLaunchKernelGGL(k_wind_sample<1>, grid, block, 0, s, c->G, c->wg, O, A.n);
+    }
+    if (W.nk >= 2) {       /* a polyline: the levels at the knots, the level at the window's end, then the coefficient planes */
+        { int rc = wind_poly_buffers(c, W.nk); if (rc) return rc; }
+        const size_t n = (size_t)A.n;
+        for (int k = 0; k < W.nk; k += 2) {
+            const bool two = k + 1 < W.nk;
+            WindSampleOut O = {{W.tk[k], two ? W.tk[k + 1] : t + dt},
+                               {c->lv_buf + (size_t)(2 * k) * n, two ? c->lv_buf + (size_t)(2 * k + 2) * n : A.u1},
+                               {c->lv_buf + (size_t)(2 * k + 1) * n, two ? c->lv_buf + (size_t)(2 * k + 3) * n : A.v1}};
+            hipLaunchKernelGGL(k_wind_sample<2>, grid, block, 0, s, c->G, c->wg, O, A.n);
+        }
+        if (W.nk % 2 == 0) {
+            WindSampleOut O = {{t + dt, 0.0}, {A.u1, nullptr}, {A.v1, nullptr}};
+            hipLaunchKernelGGL(k_wind_sample<1>, grid, block, 0, s, c->G, c->wg, O, A.n);
+        }
+        HIPCHK(c, hipGetLastError());
+        c->wind_t1 = t + dt;
+        c->wind_t1_valid = true;
+        c->P.wind_static = 0;
+        return wind_window_poly(c, t, t + dt, W.nk, W.tk, s);
     }
     if (W.three) {
         WindSampleOut O = {{W.tm, t + dt}, {c->um_buf, A.u1}, {c->vm_buf, A.v1}};
@@ -1041,7 +1178,7 @@ PX_EXPORT int32_t picles_seed(picles_ctx *c, double t0)
         /* only level 0 is read (k_seed evaluates the window at its start); the window's end is sampled at the seed time scale, whatever
          * lies between: a plain two-level window, replaced by the first step's own */
         c->wind_t1_valid = false;
-        const WindowPlan two = {false, false, 0.0};
+        const WindowPlan two = WindowPlan{};
         int rc = wind_window_sample(c, two, 0.0, c->od.timestep, true, c->stream);
         if (rc) return rc;
     }
@@ -1150,6 +1287,7 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
     {
         const KParams &P = c->P;
         bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
+        if (!P.wind_static && P.wind_nk > 1) fast = false;     /* a polyline window: the general flavours carry it (same bits: the oracle's one arithmetic) */
         Arrays A = arrays_for(c, c->cur, c->cur);
         StepLaunch L = {dim3(nblocks(nt, 256)), dim3(256), s, &c->P, &c->G, &A, 0.0, 0.0, c->clock, c->step_dt, r0, n0, r1, n1};
         launch_k_advance(L, fast, P.solver, P.wind_static != 0, c->A.pc != nullptr);      /* k_advance.hip */
@@ -1164,10 +1302,14 @@ PX_EXPORT int32_t picles_advance_rows(picles_ctx *c, int32_t which, void *stream
 }
 
 /* can this step ride on fused k_step launches? (run!-style: State zeroed first, static winds) */
-static bool step_fusable(const picles_ctx *c, int flags)
+static bool step_fusable(const picles_ctx *c, int flags, double dt)
 {
     if (flags != PICLES_STEP_ZERO_FIRST || !c->fuse_steps) return false;
     const KParams &P = c->P;
+    /* a polyline window (two or more lattice knots inside the step; host levels set by picles_set_winds_polyline) takes the plain
+     * phases: only the general flavours of the stand-alone advance evaluate one */
+    if (c->wind_grid_on ? (c->wind_grid_mode != PICLES_LATTICE_SMOOTH3 && picles_lattice_knot_times(c->wg_t0, c->wg_dt, c->clock, dt, nullptr, 0) >= 2)
+                        : (!P.wind_static && P.wind_nk > 1)) return false;
     const bool fast = P.propagation && P.input && P.dissipation && P.peak_shift && P.direction && P.n_is_2 && P.p_is_075 && P.deadband2 == 0.0;
     /* the time-varying-wind and per-node-metric flavours of the fused kernel exist for the specialised physics */
     if (c->wind_grid_on) return fast;
@@ -1225,7 +1367,7 @@ PX_EXPORT int32_t picles_begin_fused_step(picles_ctx *c, double dt)
 {
     if (!c) return -1;
     if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
-    if (!step_fusable(c, PICLES_STEP_ZERO_FIRST)) return 1;
+    if (!step_fusable(c, PICLES_STEP_ZERO_FIRST, dt)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->wind_grid_on) {
         /* device-sampled winds.  With a step pending, its remesh (done by this step's launches) needs the wind
@@ -1347,7 +1489,7 @@ PX_EXPORT int32_t picles_time_step(picles_ctx *c, double dt, int32_t flags)
     if (!c) return -1;
     if (!c->G.single_slab) return fail(c, -5, "picles_time_step needs the whole grid; slabs use begin_step/advance_rows/scatter_remesh");
     if (!(dt > 0.0)) return fail(c, -2, "dt must be positive");
-    if (step_fusable(c, flags)) {
+    if (step_fusable(c, flags, dt)) {
         /* run!-style consecutive steps: one launch per step (k_step), the scatter + remesh of the
          * previous step ride along; the last one is flushed when somebody looks */
         int rc0 = picles_begin_fused_step(c, dt);

@@ -103,6 +103,20 @@ class HipModel:
         self._ck(self.lib.picles_set_winds(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(u1), K.dptr(v1), t1),
                  "picles_set_winds")
 
+    def set_winds_polyline(self, us, vs, times):
+        """node winds at len(times) >= 2 strictly increasing times: the piecewise-linear wind through them (picles_set_winds_polyline) —
+        a gridded wind sampled at every one of its time knots inside the step and at the step's ends"""
+        import ctypes as C
+        n = len(times)
+        us = [_col(a, self.N) for a in us]
+        vs = [_col(a, self.N) for a in vs]
+        assert len(us) == n and len(vs) == n
+        PP = C.POINTER(C.c_double) * n
+        pu = PP(*[K.dptr(a) for a in us])
+        pv = PP(*[K.dptr(a) for a in vs])
+        tt = (C.c_double * n)(*[float(x) for x in times])
+        self._ck(self.lib.picles_set_winds_polyline(self.h, n, pu, pv, tt), "picles_set_winds_polyline")
+
     def set_metric(self, m11, m22, pc):
         """per-node projection diag(m11, m22) and great-circle coefficient (picles_set_metric)"""
         a = [_col(x, self.N) for x in (m11, m22, pc)]

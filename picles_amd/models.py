@@ -225,20 +225,36 @@ def gridded_wind_window(winds, grid, t, dt, last=None, rows=None):
     """the same for a GriddedWinds lattice sampled on the HOST (CPU backends; the HIP backend samples its own copy of the lattice on
     the device and builds the very same windows): returns (u0, v0, um, vm, u1, v1, tk).  time_mode "linear": the interpolant is
     piecewise linear in t, so a window without a lattice knot inside is two levels, one with a knot inside carries the level AT
-    the knot (tk: two straight segments, picles_set_winds_knot), one with two or more is refused like the library refuses it;
+    the knot (tk: two straight segments, picles_set_winds_knot); one with two or more carries a level at every knot — um, vm and tk
+    are then LISTS (the polyline, picles_set_winds_polyline); more than MAX_KNOTS is refused like the library refuses it;
     "smooth3": three levels at t, t+dt/2, t+dt (tk = None: the parabola)."""
-    from .wind_emulator import lattice_knots
+    from .wind_emulator import lattice_knot_times, MAX_KNOTS
     if winds.time_mode == "smooth3":
         return wind_window(winds, grid, t, dt, last, rows, levels=3) + (None,)
-    nk, tk = lattice_knots(float(winds.t[0]), float(winds.dt), t, dt)
-    if nk >= 2:
-        raise K.PiclesError(f"the model step [{t}, {t + dt}] contains two or more time knots of the wind lattice (spacing {winds.dt} s): "
-                            "take model steps no longer than the lattice spacing, or time_mode='smooth3'")
+    tks = lattice_knot_times(float(winds.t[0]), float(winds.dt), t, dt)
+    if len(tks) > MAX_KNOTS:
+        raise K.PiclesError(f"the model step [{t}, {t + dt}] contains {len(tks)} time knots of the wind lattice (spacing {winds.dt} s); a window "
+                            f"carries at most {MAX_KNOTS}: take shorter model steps, or time_mode='smooth3'")
     u0, v0, _, _, u1, v1 = wind_window(winds, grid, t, dt, last, rows, levels=2)
-    if nk == 0:
+    if not tks:
         return u0, v0, None, None, u1, v1, None
-    uk, vk = sample_winds(winds, grid, tk, rows)
-    return u0, v0, uk, vk, u1, v1, tk
+    if len(tks) == 1:
+        uk, vk = sample_winds(winds, grid, tks[0], rows)
+        return u0, v0, uk, vk, u1, v1, tks[0]
+    lv = [sample_winds(winds, grid, tk, rows) for tk in tks]
+    return u0, v0, [a for a, _ in lv], [b for _, b in lv], u1, v1, list(tks)
+
+
+def apply_wind_window(backend, t, dt, u0, v0, um, vm, u1, v1, tk):
+    """hand a window to a backend: two levels, three (parabola or knot form) or a polyline (um, vm, tk lists)"""
+    if um is None:
+        backend.set_winds(u0, v0, t, u1, v1, t + dt)
+    elif tk is None:
+        backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm)
+    elif isinstance(tk, (list, tuple)):
+        backend.set_winds_polyline([u0, *um, u1], [v0, *vm, v1], [t, *tk, t + dt])
+    else:
+        backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm, tk=tk)
 
 
 def _hip_backend(g, p, o, m, mask, **kw):
@@ -338,12 +354,7 @@ class WaveGrowth2D:
                 u0, v0, um, vm, u1, v1, tk = gridded_wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None))
         else:
             u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), levels=self.wind_time_levels)
-        if um is None:
-            self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
-        elif tk is None:
-            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm)
-        else:
-            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm, tk=tk)
+        apply_wind_window(self.backend, t, dt, u0, v0, um, vm, u1, v1, tk)
         # (the seeding window of a lattice is not a step's window: a knot inside it was not looked for)
         self._wind_window = None if (seeding and isinstance(self.winds, GriddedWinds)) else (t, t + dt)
         self._wind_last = (t + dt, u1, v1)

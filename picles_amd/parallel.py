@@ -21,7 +21,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi as K
-from .models import build_structs, sample_winds, wind_window, gridded_wind_window
+from .models import build_structs, sample_winds, wind_window, gridded_wind_window, apply_wind_window
 
 
 def slab_rows(Ny: int, world: int, rank: int):
@@ -323,12 +323,7 @@ class SlabModel:
         else:
             u0, v0, um, vm, u1, v1 = wind_window(self.winds, self.grid, t, dt, getattr(self, "_wind_last", None), rows,
                                                  levels=getattr(self, "wind_time_levels", 3))
-        if um is None:
-            self.backend.set_winds(u0, v0, t, u1, v1, t + dt)
-        elif tk is None:
-            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm)
-        else:
-            self.backend.set_winds(u0, v0, t, u1, v1, t + dt, um=um, vm=vm, tk=tk)
+        apply_wind_window(self.backend, t, dt, u0, v0, um, vm, u1, v1, tk)
         self._wind_last = (t + dt, u1, v1)
 
     def seed(self):

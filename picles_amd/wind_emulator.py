@@ -35,6 +35,20 @@ def lattice_knots(lat_t0, lat_dt, t, dt):
     return (2 if k0 + 1.0 < c1 - eps else 1), lat_t0 + k0 * lat_dt
 
 
+def lattice_knot_times(lat_t0, lat_dt, t, dt):
+    """all of them: the times of the lattice's knots strictly inside (t, t + dt), by the same rule (the library's picles_lattice_knot_times)"""
+    eps = 1e-9
+    c0, c1 = (t - lat_t0) / lat_dt, (t + dt - lat_t0) / lat_dt
+    out, k = [], float(np.floor(c0 + eps)) + 1.0
+    while k < c1 - eps:
+        out.append(lat_t0 + k * lat_dt)
+        k += 1.0
+    return out
+
+
+MAX_KNOTS = 8      # PICLES_MAX_KNOTS: knots one window carries
+
+
 class GriddedWinds:
     """time_mode "linear": the model follows the interpolant itself inside a step, kinks at the lattice's time knots included —
     what the reference does when its winds come from wind_interpolator (the RHS evaluates linear_interpolation((x,y,t), u) at

@@ -38,6 +38,7 @@ def lib(kind: str = "libm") -> C.CDLL:
         "picles_oracle_set_winds": (C.c_int32, [VP, DP, DP, D, DP, DP, D]),
         "picles_oracle_set_winds3": (C.c_int32, [VP, DP, DP, D, DP, DP, DP, DP, D]),
         "picles_oracle_set_winds_knot": (C.c_int32, [VP, DP, DP, D, DP, DP, D, DP, DP, D]),
+        "picles_oracle_set_winds_polyline": (C.c_int32, [VP, C.c_int32, C.POINTER(DP), C.POINTER(DP), DP]),
         "picles_oracle_seed": (C.c_int32, [VP, D]),
         "picles_oracle_advance": (C.c_int32, [VP, D]),
         "picles_oracle_remesh": (C.c_int32, [VP, D]),
@@ -153,6 +154,18 @@ class OracleModel:
             assert rc == 0, rc
             return
         self.L.picles_oracle_set_winds3(self.h, K.dptr(u0), K.dptr(v0), t0, K.dptr(um), K.dptr(vm), K.dptr(u1), K.dptr(v1), t1)
+
+    def set_winds_polyline(self, us, vs, times):
+        def col(a):
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, order="F"))
+            assert a.size == self.N, (a.size, self.N)
+            return a
+        n = len(times)
+        us, vs = [col(a) for a in us], [col(a) for a in vs]
+        PP = C.POINTER(C.c_double) * n
+        rc = self.L.picles_oracle_set_winds_polyline(self.h, n, PP(*[K.dptr(a) for a in us]), PP(*[K.dptr(a) for a in vs]),
+                                                     (C.c_double * n)(*[float(x) for x in times]))
+        assert rc == 0, rc
 
     def set_metric(self, m11, m22, pc):
         a = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, order="F")) for x in (m11, m22, pc)]

@@ -383,8 +383,9 @@ def winds_lattice(dx, dy, lat_dt, T_end, U=11.0, V=6.0, amp_t=0.08):
     tk = np.arange(0.0, T_end + 0.5 * lat_dt, lat_dt)
     # (amplitude chosen so that the tolerance-respecting steppers (abstol 1e-4, reltol 1e-3) still sit within the stated 1e-3 of the
     # converged solution: a zig-zag of +-30 % is followed to 3e-3 only, and flips remesh branches at single nodes)
-    zu = np.array([0.0, 1.0, -0.7, 0.9, -1.0, 0.7, -0.4, 1.0, -0.6, 0.4, -0.9, 1.0, 0.0, 0.7, -0.7])[:tk.size]
-    zv = np.array([0.0, -0.7, 0.6, -0.9, 0.8, -0.4, 1.0, -1.0, 0.4, -0.6, 0.9, -0.7, 0.0, -0.4, 0.7])[:tk.size]
+    zu = np.array([0.0, 1.0, -0.7, 0.9, -1.0, 0.7, -0.4, 1.0, -0.6, 0.4, -0.9, 1.0, 0.0, 0.7, -0.7])
+    zv = np.array([0.0, -0.7, 0.6, -0.9, 0.8, -0.4, 1.0, -1.0, 0.4, -0.6, 0.9, -0.7, 0.0, -0.4, 0.7])
+    zu, zv = np.resize(zu, tk.size), np.resize(zv, tk.size)     # (longer series repeat the pattern)
     gu, gv = 1.0 + amp_t * zu, 1.0 + amp_t * zv
     assert gu.size == tk.size
     X, Y = np.meshgrid(xk, yk, indexing="ij")
@@ -425,6 +426,10 @@ CASES = {
     # 700-second knots under 10-minute steps: the knot wanders through the step (s = 1/6, 1/3, 1/2, 2/3, 5/6, none)
     "full_lattice_700": dict(dx=2000.0, dy=2500.0, DT=600.0, timestep=600.0, C_phi=1.81e-5, periodic_boundary=False,
                              lne_max=math.log(27), sw=ALL_ON, tfac=None, lattice_dt=700.0),
+    # 250-second knots under 10-minute steps: two or three knots inside EVERY step (250, 500 | 750, 1000 | 1250, 1500, 1750 | ...) — wind
+    # data finer in time than the model step; the window is a polyline with a kink at every knot
+    "full_lattice_250": dict(dx=2000.0, dy=2500.0, DT=600.0, timestep=600.0, C_phi=1.81e-5, periodic_boundary=False,
+                             lne_max=math.log(27), sw=ALL_ON, tfac=None, lattice_dt=250.0),
 }
 STEPS = (1, 3, 6)
 

@@ -117,27 +117,28 @@ def test_random_scenario_in_slabs_bitwise(seed):
     assert_bitwise(S, ref, f"seed {seed} ({cfg.desc}), {world} slabs, halo {reach}")
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_device_sampled_winds_in_slabs_bitwise(world):
+@pytest.mark.parametrize("world,dts", [(2, None), (3, None), (2, (600.0, 2000.0, 600.0, 600.0, 3000.0, 600.0))])
+def test_device_sampled_winds_in_slabs_bitwise(world, dts):
     """gridded (time-varying, partly calm) winds: every slab samples its own rows from the lattice on the device and
-    runs the fused time-varying step; the result equals the single context bitwise"""
+    runs the fused time-varying step; the result equals the single context bitwise.  `dts`: steps that hold two to four of the
+    lattice's 900-second knots among the ordinary ones — polyline windows, which take the plain phases in every slab"""
     from test_wind_grid import _calm_lattice, _cfg
     from picles_amd.wind_emulator import wind_interpolator
     w = wind_interpolator(_calm_lattice())
     cfg = _cfg(w)
-    n_steps = 7
+    dts = dts or (cfg.Δt,) * 7
     one = SlabModel(cfg.model, 0, 1, device=0)
     one.seed()
-    for _ in range(n_steps):
-        one.time_step(cfg.Δt)
+    for dt in dts:
+        one.time_step(dt)
     ref = one.get_state()
     assert one.backend.get_counters()["reseeds"] > 0
-    slabs = [SlabModel(_cfg(w).model, r, world, device=0, halo_rows=2, exchange=_NoExchange()) for r in range(world)]
+    slabs = [SlabModel(_cfg(w).model, r, world, device=0, halo_rows=(2 if max(dts) <= 600.0 else 6), exchange=_NoExchange()) for r in range(world)]
     for s in slabs:
         s._comm_warm = True
         s.seed()
-    for k in range(n_steps):
-        _step_all(slabs, cfg.Δt, slabs[0].periodic_y, fused_ok=True)
+    for dt in dts:
+        _step_all(slabs, dt, slabs[0].periodic_y, fused_ok=True)
     S = np.concatenate([s.get_state() for s in slabs], axis=1)
     assert sum(s.backend.get_counters()["halo_overflow"] for s in slabs) == 0
     assert_bitwise(S, ref, f"{world} slabs under device-sampled winds")

@@ -131,7 +131,10 @@ def test_stand_alone_advance_reloads_its_arguments_in_every_flavour():
         general_auto = name.startswith("_Z9k_advanceILb0E") and name.split("EEv")[0].endswith("ELb1")
         # (40, not 20: the time-varying flavours keep the knot position of a gridded wind's window since round 4, and the polynomial
         # constants pinned to scalar registers at their use (pmath.h, pm_sc) trade vector for scalar pressure: 22 - 26)
-        assert u["sspill"] <= (110 if general_auto else 40), (name, u)
+        # (the general-physics flavours — two waves per SIMD, none of them on a timed path — also carry the polyline windows of gridded
+        # winds with several time knots inside a step since round 4: a pointer, a stride and a count more in scalars, 52 - 60 spills)
+        general = name.startswith("_Z9k_advanceILb0E")
+        assert u["sspill"] <= (110 if general_auto else (72 if general else 40)), (name, u)
         assert u["scratch"] <= 96, (name, u)
 
 

@@ -85,3 +85,43 @@ def test_sphere_unobserved_run_is_fused_and_bitwise(solver):
     live = ((sto & 1) == 1) & (ono == 1)
     for c in range(5):
         assert_bitwise(zg[..., c][live], zo[..., c][live], f"z[{c}]")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["DP5", "AutoTsit5"])
+def test_sphere_under_a_polyline_wind_window_bitwise(solver):
+    """a wind with three time knots inside the two-hour step (picles_set_winds_polyline: five levels) on the lon / lat mesh: the
+    per-node-metric general flavour of the stand-alone advance carries the polyline; State and particles equal oracle B's bit for bit,
+    and oracle A (the literal lerp of the segment the stage time falls into) agrees within the stated tolerance"""
+    from picles_amd import _capi as K
+    from picles_amd.simulations import Simulation, initialize_simulation
+    from helpers import make_model
+    def mk():
+        c = configs.sphere_aqua(nx=46, ny=31, n_steps=2)
+        c.model["ODEsets"].solver = solver
+        c.model["winds_static"] = False
+        return c
+    cfg = mk()
+    ms = [make_model(mk(), b) for b in ("hip", ("pmath", 1), ("libm", 0))]
+    X, Y = ms[0].grid.data.x, ms[0].grid.data.y
+    u0, v0 = cfg.model["winds"].u(X, Y, 0.0), cfg.model["winds"].v(X, Y, 0.0)
+    DT = cfg.Δt
+    windows = [([0.0, 1500.0, 4000.0, 6100.0, DT], [1.0, 1.1, 0.85, 1.05, 0.95], [1.0, 0.9, 1.2, 0.8, 1.1]),
+               ([DT, DT + 900.0, DT + 5000.0, 2 * DT], [0.95, 1.15, 0.9, 1.0], [1.1, 1.0, 0.7, 1.0])]
+    S = []
+    for m in ms:
+        initialize_simulation(Simulation(m, Δt=DT, stop_time=1.0))
+        for times, fu, fv in windows:
+            m.backend.set_winds_polyline([u0 * f for f in fu], [v0 * f for f in fv], times)
+            m.backend.time_step(DT, K.STEP_ZERO_FIRST)
+        S.append(np.array(m.backend.get_state()))
+    assert np.abs(S[1]).max() > 0
+    assert_bitwise(S[0], S[1], "State under polyline windows, HIP vs oracle B")
+    zg, ong, _, _ = ms[0].backend.get_particles()
+    zo, ono, _, sto = ms[1].backend.get_particles()
+    assert_bitwise(ong, ono, "on")
+    live = ((sto & 1) == 1) & (ono == 1)
+    for c in range(5):
+        assert_bitwise(zg[..., c][live], zo[..., c][live], f"z[{c}]")
+    e_a, e_b = S[2].reshape(S[1].shape)[..., 0], S[1][..., 0]
+    assert np.abs(e_a - e_b).max() < 1e-3 * np.abs(e_b).max()

@@ -43,7 +43,12 @@ TOL = {"pic_only": (1e-12, 1e-12), "full_nonstiff": (1e-3, 5e-4), "full_stiff": 
        # What the (abstol 1e-4, reltol 1e-3) steppers make of a forcing with kinks is their own business: 900-second knots under
        # 10-minute steps stay within the stated 1e-3 (measured 2.1e-4, DP5 1.0e-3), a knot that wanders through the step costs 2.4e-3,
        # a kink in the middle of every 20-minute step 4.3e-3 (DP5: 1.8e-2 after six steps, in the strong-wind rows)
-       "full_lattice_900": (1e-3, 5e-4), "full_lattice_600_dt1200": (8e-3, 4e-3), "full_lattice_700": (4e-3, 2e-3)}
+       "full_lattice_900": (1e-3, 5e-4), "full_lattice_600_dt1200": (8e-3, 4e-3), "full_lattice_700": (4e-3, 2e-3),
+       # wind data finer in time than the model step: 250-second knots under 10-minute steps, two or three kinks inside every step —
+       # the window is a polyline (picles_set_winds_polyline / the device sampler: one level per knot).  Exact as a window (8e-7 /
+       # 1.6e-6 / 9.4e-6 with the stepper's error taken out); two or three kinks of 8-16 % per step cost the (1e-4, 1e-3) steppers
+       # 6.7e-3 (DP5) / 7.4e-3 (Tsit5, AutoTsit5) at the worst node
+       "full_lattice_250": (1e-2, 5e-3)}
 # DP5 over a 20-minute step is solver-limited, not wind-limited: 2.0e-3 at the worst node (median 1.4e-4) with abstol 1e-4 /
 # reltol 1e-3, 7e-6 with the tolerances tightened (test_what_the_third_wind_level_buys); the default solver is within 1.6e-4
 TOL_SOLVER = {("full_tvar", "DP5"): (3e-3, 1.5e-3), ("full_lattice_900", "DP5"): (2e-3, 1e-3), ("full_lattice_600_dt1200", "DP5"): (3e-2, 1.5e-2)}
@@ -116,7 +121,8 @@ def _rel(a, ref, floor):
                                          ("full_tvar", "DP5"), ("full_tvar", "AutoTsit5"), ("full_tvar_fast", "AutoTsit5"),
                                          ("full_lattice_900", "DP5"), ("full_lattice_900", "AutoTsit5"),
                                          ("full_lattice_600_dt1200", "DP5"), ("full_lattice_600_dt1200", "AutoTsit5"),
-                                         ("full_lattice_700", "Tsit5"), ("full_lattice_700", "AutoTsit5")])
+                                         ("full_lattice_700", "Tsit5"), ("full_lattice_700", "AutoTsit5"),
+                                         ("full_lattice_250", "DP5"), ("full_lattice_250", "Tsit5"), ("full_lattice_250", "AutoTsit5")])
 def test_whole_step_against_independent_restatement(name, solver, backend):
     fx = np.load(GOLD / f"step2d_{name}.npz")
     cfg = _cfg(name, solver)
@@ -237,7 +243,7 @@ def test_config5_forcing_through_a_smooth3_lattice(backend):
             m.clock.time += cfg.Δt
 
 
-LATTICE_CASES = ("full_lattice_900", "full_lattice_600_dt1200", "full_lattice_700")
+LATTICE_CASES = ("full_lattice_900", "full_lattice_600_dt1200", "full_lattice_700", "full_lattice_250")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -246,9 +252,10 @@ def test_gridded_winds_with_time_knots_inside_the_step(name, backend):
     """wind_interpolator is linear_interpolation((x,y,t), u) (Utils/WindEmulator.jl:18-43) and the RHS calls
     it at every stage time (particle_waves_v5.jl:494-495): a time knot inside [t, t+Δt] is a kink the solver sees.  The fixtures
     integrate the lattice's own interpolant (900-second knots under 600-second steps; 600-second knots under config 5's 1200-second
-    step; 700-second knots wandering through 600-second steps).  With the stepper's error taken out (abstol 1e-10, reltol 1e-9) the
-    boundary's window — two straight segments meeting at the knot — reproduces them to the converged solutions' own accuracy.
-    Measured (oracle A): 1.4e-6 / 3.8e-6 / 1.9e-6; the HIP path samples the lattice on the device (LINEAR mode)."""
+    step; 700-second knots wandering through 600-second steps; 250-second knots, two or three inside every 600-second step).  With
+    the stepper's error taken out (abstol 1e-10, reltol 1e-9) the boundary's window — straight segments meeting at the knots —
+    reproduces them to the converged solutions' own accuracy.
+    Measured (oracle A): 1.4e-6 / 3.8e-6 / 1.9e-6 / 9.4e-6; the HIP path samples the lattice on the device (LINEAR mode)."""
     err = _state_errors(name, "AutoTsit5", backend, 3, True)
     assert max(err.values()) < 2e-5, (name, err)
 
@@ -269,11 +276,13 @@ def test_a_window_that_ignores_the_knot_is_far_outside_the_tolerance(name, monke
 
 def test_lattice_fixtures_have_knots_where_they_claim():
     from picles_amd.wind_emulator import lattice_knots
+    from picles_amd.wind_emulator import lattice_knot_times
     for name, dt, lat_dt, want in (("full_lattice_900", 600.0, 900.0, [0, 1, 0, 0, 1, 0]), ("full_lattice_600_dt1200", 1200.0, 600.0, [1] * 6),
-                                   ("full_lattice_700", 600.0, 700.0, [0, 1, 1, 1, 1, 1])):
+                                   ("full_lattice_700", 600.0, 700.0, [0, 1, 1, 1, 1, 1]), ("full_lattice_250", 600.0, 250.0, [2, 2, 3, 2, 2, 2])):
         fx = np.load(GOLD / f"step2d_{name}.npz")
         assert fx["lat_t"][1] - fx["lat_t"][0] == lat_dt and GEN.CASES[name]["DT"] == dt
-        assert [lattice_knots(0.0, lat_dt, k * dt, dt)[0] for k in range(6)] == want
+        assert [len(lattice_knot_times(0.0, lat_dt, k * dt, dt)) for k in range(6)] == want
+        assert [lattice_knots(0.0, lat_dt, k * dt, dt)[0] for k in range(6)] == [min(w, 2) for w in want]
         # the zig-zag: successive knots differ by at least 4 % of the wind somewhere
         assert np.abs(np.diff(fx["lat_u"], axis=2)).max() > 0.04 * np.abs(fx["lat_u"]).max()
 

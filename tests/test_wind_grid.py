@@ -61,13 +61,44 @@ def test_knot_classifier_python_and_c_agree():
     assert lattice_knots(0.0, 900.0, 1200.0, 600.0)[0] == 0 and lattice_knots(0.0, 900.0, 600.0, 600.0) == (1, 900.0)
 
 
-def test_host_sampled_window_refuses_two_knots_in_one_step():
+def test_knot_lists_python_and_c_agree():
+    """wind_emulator.lattice_knot_times against picles_lattice_knot_times: same counts, same times to the bit; the capped classifier
+    is min(count, 2) of it"""
+    import ctypes as C
+    from picles_amd.wind_emulator import lattice_knot_times
+    lib = K.load()
+    rng = np.random.default_rng(11)
+    cases = [(0.0, 250.0, 600.0 * k, 600.0) for k in range(12)] + [(0.0, 900.0, 0.0, 2000.0), (0.0, 900.0, 0.0, 9000.0), (0.0, 100.0, 50.0, 1000.0)] + \
+            [(float(rng.uniform(-1e4, 1e4)), float(rng.uniform(50, 5e3)), float(rng.uniform(0, 1e5)), float(rng.uniform(10, 2e4))) for _ in range(300)]
+    counts = set()
+    for t0, ldt, t, dt in cases:
+        buf = (C.c_double * 16)()
+        n = lib.picles_lattice_knot_times(t0, ldt, t, dt, buf, 16)
+        tks = lattice_knot_times(t0, ldt, t, dt)
+        assert n == len(tks), (t0, ldt, t, dt, n, tks)
+        assert list(buf[:min(n, 16)]) == tks[:16]
+        assert all(t < x < t + dt for x in tks) and all(b > a for a, b in zip(tks, tks[1:]))
+        assert lib.picles_lattice_knots(t0, ldt, t, dt, None) == min(n, 2) == lattice_knots(t0, ldt, t, dt)[0]
+        assert lib.picles_lattice_knot_times(t0, ldt, t, dt, None, 0) == n
+        counts.add(min(n, 9))
+    assert {0, 1, 2, 3, 9} <= counts
+    assert lattice_knot_times(0.0, 250.0, 1200.0, 600.0) == [1250.0, 1500.0, 1750.0]
+
+
+def test_host_sampled_window_carries_several_knots_and_refuses_too_many():
+    """[0, 2000] over 900-second knots holds two of them: the host layer hands the CPU backends a polyline (the levels at 900 and 1800);
+    oracle A (the literal lerp of the segment) and oracle B (the kernel's sum form) agree to rounding.  Nine knots in one step are refused."""
     lat, _, _ = _lattice()
     w = wind_interpolator(lat)
-    o = make_model(_cfg(w), ("pmath", 1))
-    initialize_simulation(Simulation(o, Δt=2000.0, stop_time=1.0))       # seeding looks at level 0 only: no refusal there
-    with pytest.raises(K.PiclesError, match="two or more time knots"):
-        time_step(o, 2000.0, zero_first=True)                            # [0, 2000] holds the knots at 900 and 1800
+    a = make_model(_cfg(w), ("libm", 0))
+    b = make_model(_cfg(w), ("pmath", 1))
+    for m in (a, b):
+        initialize_simulation(Simulation(m, Δt=2000.0, stop_time=1.0))   # seeding looks at level 0 only
+        time_step(m, 2000.0, zero_first=True)                            # [0, 2000] holds the knots at 900 and 1800
+    assert np.abs(a.State).max() > 0
+    np.testing.assert_allclose(a.State, b.State, rtol=1e-3, atol=1e-9)
+    with pytest.raises(K.PiclesError, match="at most 8"):
+        time_step(b, 9000.0, zero_first=True)
 
 
 def _cfg(w):
@@ -104,19 +135,71 @@ def test_device_sampler_bitwise_and_run_matches_oracle():
 
 
 @pytest.mark.gpu
-def test_device_lattice_refuses_a_step_with_two_knots_and_stays_usable():
+def test_device_lattice_refuses_a_step_with_too_many_knots_and_stays_usable():
     lat, _, _ = _lattice()
     w = wind_interpolator(lat)
     g = make_model(_cfg(w), "hip")
     o = make_model(_cfg(w), ("pmath", 1))
     for m in (g, o):
         initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
-    with pytest.raises(K.PiclesError, match="two or more time knots"):
-        time_step(g, 2000.0, zero_first=True)
+    with pytest.raises(K.PiclesError, match="at most 8"):
+        time_step(g, 9000.0, zero_first=True)          # nine knots inside one step
     for k in range(3):           # the refused step changed nothing: the run continues bit for bit
         for m in (g, o):
             time_step(m, 600.0, zero_first=True)
     assert_bitwise(g.State, o.State, "State after a refused step")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["DP5", "Tsit5", "AutoTsit5"])
+def test_steps_with_several_knots_run_as_polyline_windows_between_fused_steps(solver):
+    """900-second knots: 600-second steps hold none or one (fused launches, two- and three-level windows), a 2000-second step holds two
+    and a 3000-second step three or four (polyline windows: the plain phases, general flavour of the stand-alone advance, the levels
+    sampled on the device at every knot).  The run switches back and forth with nobody looking in between; State, particles and
+    counters equal the oracle's (host-sampled windows through models.gridded_wind_window) bit for bit."""
+    lat = _calm_lattice() if solver == "Tsit5" else _lattice()[0]
+    w = wind_interpolator(lat)
+    def mk():
+        c = _cfg(w)
+        c.model["ODEsets"].solver = solver
+        return c
+    g = make_model(mk(), "hip")
+    o = make_model(mk(), ("pmath", 1))
+    for m in (g, o):
+        initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
+    for dt in (600.0, 600.0, 2000.0, 600.0, 3000.0, 2000.0, 600.0, 600.0):
+        for m in (g, o):
+            time_step(m, dt, zero_first=True)
+    assert_bitwise(g.State, o.State, "State after the mixed run")
+    zg, ong, _, stg = g.backend.get_particles()
+    zo, ono, _, sto = o.backend.get_particles()
+    assert_bitwise(ong, ono, "on"); assert_bitwise(stg, sto, "status")
+    st = ((sto & 1) == 1) & (ono == 1)
+    for c in range(5):
+        assert_bitwise(zg[..., c][st], zo[..., c][st], f"z[{c}]")
+    cg, co = g.backend.get_counters(), o.backend.get_counters()
+    for key in ("particles_advanced", "rhs_evals", "reseeds"):
+        assert cg[key] == co[key], (key, cg[key], co[key])
+
+
+@pytest.mark.gpu
+def test_host_levels_polyline_equals_the_device_sampled_one():
+    """picles_set_winds_polyline with the levels a host would sample (NumPy interpolant at t, the knots, t + dt) against the device
+    sampler's own polyline window of the same step: the same bits"""
+    lat, _, _ = _lattice()
+    w = wind_interpolator(lat)
+    g = make_model(_cfg(w), "hip")
+    h = make_model(_cfg(w), "hip")
+    for m in (g, h):
+        initialize_simulation(Simulation(m, Δt=600.0, stop_time=1.0))
+        time_step(m, 600.0, zero_first=True)
+    X, Y = g.grid.data.x, g.grid.data.y
+    time_step(g, 3000.0, zero_first=True)             # [600, 3600]: knots at 900, 1800, 2700 — sampled on the device
+    times = [600.0, 900.0, 1800.0, 2700.0, 3600.0]
+    h.backend.set_winds_polyline([w.u(X, Y, t) for t in times], [w.v(X, Y, t) for t in times], times)
+    h.backend.time_step(3000.0, K.STEP_ZERO_FIRST)
+    assert_bitwise(h.backend.get_state(), g.backend.get_state(), "State")
+    assert np.abs(g.backend.get_state()).max() > 0
 
 
 @pytest.mark.gpu
