@@ -114,3 +114,69 @@ def test_random_scenario_bitwise(seed):
     cg, co = g.backend.get_counters(), o.backend.get_counters()
     for key in ("particles_advanced", "rhs_evals", "steps_accepted", "steps_rejected", "reseeds", "max_reach"):
         assert cg[key] == co[key], (seed, key, cg[key], co[key])
+
+
+N_LATTICE_SEEDS = int(__import__("os").environ.get("PICLES_FUZZ_LATTICE_SEEDS", "48"))
+
+
+def lattice_scenario(seed):
+    """the time-varying variant of a random scenario with its wind closures tabulated on a lattice whose time spacing is a random
+    fraction of the model step (Δt/5.3 .. Δt/0.7: none to five knots inside a step, varying from step to step) — the gridded-wind path
+    with two-level, knot-form and polyline windows in one run, on every physics flavour, mask, periodicity and solver of the fuzzer"""
+    from picles_amd.configs import closure_lattice
+    k = seed
+    while True:                                   # the next seed whose scenario has time-varying winds
+        cfg = scenario(10_000 + k)
+        if not cfg.model["winds_static"]:
+            break
+        k += 1000
+    rng = np.random.default_rng(77 + seed)
+    kps = float(rng.choice([0.7, 1.0, 1.6, 2.0, 2.4, 3.0, 3.7, 5.3]))
+    cfg = closure_lattice(cfg, cfg.n_steps, knots_per_step=kps)
+    cfg.model["winds"].time_mode = "linear"       # the interpolant itself, kinks included
+    cfg.model["ODEsets"].solver = ["DP5", "Tsit5", "AutoTsit5"][seed % 3]
+    cfg.desc += f" lattice knots/step={kps} {cfg.model['ODEsets'].solver}"
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(N_LATTICE_SEEDS))
+def test_random_scenario_on_a_lattice_with_knots_inside_the_steps_bitwise(seed):
+    from picles_amd.wind_emulator import lattice_knot_times
+    cfg = lattice_scenario(seed)
+    g, o = make_model(lattice_scenario(seed), "hip"), make_model(lattice_scenario(seed), ORACLE)
+    for m in (g, o):
+        initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    assert_bitwise(g.State, o.State, f"seed {seed} ({cfg.desc}): State after init")
+    for k in range(cfg.n_steps):
+        for m in (g, o):
+            if cfg.mode == "run":
+                time_step(m, cfg.Δt, zero_first=True)
+            else:
+                movie_time_step(m, cfg.Δt)
+        if g.backend.get_counters()["halo_overflow"] > 0:
+            assert o.backend.get_counters()["max_reach"] > 64
+            return
+    a, b = (g.State, o.State) if cfg.mode == "run" else (g.MovieState, o.MovieState)
+    assert_bitwise(a, b, f"seed {seed} ({cfg.desc}): final State")
+    zg, ong, _, stg = g.backend.get_particles()
+    zo, ono, _, sto = o.backend.get_particles()
+    assert_bitwise(ong, ono, "on")
+    assert_bitwise(stg, sto, "status")
+    stepped = ((sto & 1) == 1) & (ono == 1)
+    for c in range(5):
+        assert_bitwise(zg[..., c][stepped], zo[..., c][stepped], f"seed {seed}: z[{c}]")
+    cg, co = g.backend.get_counters(), o.backend.get_counters()
+    for key in ("particles_advanced", "rhs_evals", "steps_accepted", "steps_rejected", "reseeds", "max_reach"):
+        assert cg[key] == co[key], (seed, key, cg[key], co[key])
+
+
+def test_lattice_scenarios_cover_every_window_form():
+    """(host arithmetic only) over the seeds of the test above the steps hold 0, 1, 2, 3 and more knots"""
+    from picles_amd.wind_emulator import lattice_knot_times
+    seen = set()
+    for seed in range(min(N_LATTICE_SEEDS, 24)):
+        cfg = lattice_scenario(seed)
+        w = cfg.model["winds"]
+        for k in range(cfg.n_steps):
+            seen.add(min(len(lattice_knot_times(float(w.t[0]), float(w.dt), k * cfg.Δt, cfg.Δt)), 4))
+    assert seen == {0, 1, 2, 3, 4}, seen
