@@ -99,6 +99,24 @@ def test_native_ring_mixed_step_kinds_with_device_winds_bitwise():
     assert_bitwise(ring.backend.get_movie_state(), plain.backend.get_movie_state(), "MovieState")
 
 
+def test_native_ring_steps_with_several_lattice_knots_bitwise():
+    """1200-second knots: 600-second steps hold none or one (fused launches in the ring), 3000- and 4000-second steps hold two to four —
+    polyline windows, which the native ring runs through its plain phases (edge advance, exchange, interior advance, scatter + remesh)
+    with the general flavour of the stand-alone advance; the ring of one equals the plain context bit for bit"""
+    cfg = _lattice_box()
+    ring = SlabModel(cfg.model, 0, 1, device=0, halo_rows=8, ring_of_one=True)
+    assert ring.native
+    ring.seed()
+    plain = _plain(_lattice_box())
+    for dt, n in ((600.0, 2), (3000.0, 1), (600.0, 1), (4000.0, 1), (600.0, 2)):
+        ring.run_steps(dt, n, K.STEP_ZERO_FIRST)
+        for _ in range(n):
+            plain.upload_winds(plain.clock.time, dt)
+            plain.backend.time_step(dt, K.STEP_ZERO_FIRST)
+            plain.clock.time += dt
+    _same(ring, plain)
+
+
 def test_native_ring_full_width_rows_4096():
     """row length of the BASELINE box (4096 nodes, the 197 KB halo block of DESIGN §6) at 1/16 of its height"""
     n = 4096
