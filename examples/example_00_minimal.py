@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 
 from picles_amd import fetch_relations as FetchRelations
-from picles_amd.core_2D import ParticleDefaults
+from picles_amd.models import ParticleDefaults
 from picles_amd.grids import TwoDCartesianGridMesh
 from picles_amd.models import WaveGrowth2D
 from picles_amd.particle_waves_v5 import ODEParameters, ODESettings, particle_equations

@@ -203,7 +203,7 @@ def sphere_aqua(nx=91, ny=61, n_steps=8, with_land=True):
     psys = particle_equations(u, v, γ=Const_ID.γ, q=Const_ID.q, IDConstants=Const_ID)
     pars = dict(r_g=ODEpars["r_g"], C_α=Const_Scg.C_alpha, C_φ=Const_ID.c_β, C_e=Const_ID.C_e, g=9.81)
     ws = FetchRelations.MinimalWindsea(U10, V10, DT)
-    from .core_2D import ParticleDefaults
+    from .models import ParticleDefaults
     sets = ODESettings(Parameters=pars, log_energy_minimum=math.log(ws["E"]), log_energy_maximum=math.log(27),
                        saving_step=DT, timestep=DT, total_time=6 * DAYS, adaptive=True, dt=1e-3, dtmin=1e-4, force_dtmin=True)
     return SimpleNamespace(

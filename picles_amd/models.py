@@ -8,15 +8,28 @@ the HIP library and nothing else.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from types import SimpleNamespace
 
 import numpy as np
 
 from . import _capi as K
 from . import fetch_relations as FetchRelations
-from .core_2D import ParticleDefaults
 from .grids import TwoDCartesianGridMesh, TwoDSphericalGridMesh, N_Periodic, make_boundary_lists
 from .particle_waves_v5 import ODESettings, ParticleSystem2D
+
+
+@dataclass
+class ParticleDefaults:
+    """the fixed default particle of a model (src/Operators/core_2D.jl:40-58)"""
+    lne: float
+    c̄_x: float
+    c̄_y: float
+    x: float = 0.0
+    y: float = 0.0
+
+    def as_vector(self):
+        return [self.lne, self.c̄_x, self.c̄_y, self.x, self.y]
 
 
 class Clock:

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from picles_amd import fetch_relations as FetchRelations
-from picles_amd.core_2D import ParticleDefaults
+from picles_amd.models import ParticleDefaults
 from picles_amd.grids import TwoDCartesianGridMesh, TwoDSphericalGridMesh
 from picles_amd.particle_waves_v5 import ODEParameters, ODESettings, particle_equations
 from picles_amd.simulations import Simulation, initialize_simulation
