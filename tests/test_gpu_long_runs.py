@@ -3,7 +3,7 @@ holds them at their stated SIZES for 3-10 steps.  A long run is where the sea de
 and three, the energy cap clamps, particles switch off and on along the calm edge, the five rotating reach / order buffers and the
 fused chain (launch k scatters and remeshes step k-1) go round many times.  The HIP path runs unobserved (one fused launch per step)
 between the checkpoints; State at every checkpoint, the particles and the counters at the end equal oracle B's bit for bit.
-Grid side PICLES_LONGRUN_N (default 96; 1024 / 4096 / 2048 are the stated sizes — a one-off run at 1024 is in
+Grid side PICLES_LONGRUN_N (default 64: half a minute of the suite; 1024 / 4096 / 2048 are the stated sizes — a one-off run at 1024 is in
 profiles/r4_long_runs_pytest.log)."""
 import os
 
@@ -15,7 +15,7 @@ from helpers import assert_bitwise
 from test_gpu_fullsize import _init, _model, _same_particles, _step
 
 pytestmark = pytest.mark.gpu
-N = int(os.environ.get("PICLES_LONGRUN_N", "96"))
+N = int(os.environ.get("PICLES_LONGRUN_N", "64"))
 
 
 def _long(cfg_fn, n_steps, checkpoints, min_reach):
