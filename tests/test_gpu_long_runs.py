@@ -12,10 +12,20 @@ import pytest
 
 from picles_amd import configs
 from helpers import assert_bitwise
-from test_gpu_fullsize import _init, _model, _same_particles, _step
+from picles_amd import models
+from helpers import make_model, oracle_factory
+from test_gpu_fullsize import THREADS, _init, _same_particles, _step
 
 pytestmark = pytest.mark.gpu
 N = int(os.environ.get("PICLES_LONGRUN_N", "64"))
+
+
+def _model(cfg, backend):
+    if backend == "hip":
+        return make_model(cfg, "hip")
+    kind, order = backend
+    # (a small grid on many threads spends its time in the team's barriers: 0.25 s per step with 16 threads at 64² on the GPU box)
+    return models.WaveGrowth2D(**cfg.model, backend_factory=oracle_factory(kind, order, threads=max(1, min(THREADS, N * N // 4096))))
 
 
 def _long(cfg_fn, n_steps, checkpoints, min_reach):
