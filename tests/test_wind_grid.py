@@ -200,6 +200,23 @@ def test_host_levels_polyline_equals_the_device_sampled_one():
     h.backend.time_step(3000.0, K.STEP_ZERO_FIRST)
     assert_bitwise(h.backend.get_state(), g.backend.get_state(), "State")
     assert np.abs(g.backend.get_state()).max() > 0
+    # the most a window carries: eight knots (ten levels) — against oracle B, bit for bit; nine are refused and change nothing
+    o = make_model(_cfg(w), ("pmath", 1))
+    initialize_simulation(Simulation(o, Δt=600.0, stop_time=1.0))
+    time_step(o, 600.0, zero_first=True)
+    o.backend.set_winds_polyline([w.u(X, Y, t) for t in times], [w.v(X, Y, t) for t in times], times)
+    o.backend.time_step(3000.0, K.STEP_ZERO_FIRST)
+    t10 = [3600.0 + 250.0 * k for k in range(10)]
+    for m in (h, o):
+        m.backend.set_winds_polyline([w.u(X, Y, t) for t in t10], [w.v(X, Y, t) for t in t10], t10)
+        m.backend.time_step(t10[-1] - t10[0], K.STEP_ZERO_FIRST)
+    assert_bitwise(h.backend.get_state(), o.backend.get_state(), "State under a ten-level window")
+    t11 = [t10[-1] + 200.0 * k for k in range(11)]
+    with pytest.raises(K.PiclesError, match="at most 8"):
+        h.backend.set_winds_polyline([w.u(X, Y, t) for t in t11], [w.v(X, Y, t) for t in t11], t11)
+    with pytest.raises(K.PiclesError, match="increase strictly"):
+        h.backend.set_winds_polyline([w.u(X, Y, t) for t in t10], [w.v(X, Y, t) for t in t10], t10[:5] + t10[4:9])
+    assert_bitwise(h.backend.get_state(), o.backend.get_state(), "State after the refused windows")
 
 
 @pytest.mark.gpu
