@@ -82,3 +82,40 @@ def test_hostile_scenario_neither_faults_nor_lies(seed):
     if overflow == 0 and co["max_reach"] <= 64:
         for key in ("rhs_evals", "steps_accepted", "steps_rejected", "reseeds", "maxiters_hits"):
             assert cg[key] == co[key], (seed, cfg.desc, key, cg[key], co[key])
+
+
+N_POLY = int(__import__("os").environ.get("PICLES_HOSTILE_POLY_SEEDS", "24"))
+
+
+@pytest.mark.parametrize("seed", range(N_POLY))
+def test_hostile_winds_through_polyline_windows(seed):
+    """the hostile wind fields (calm halves, NaN patches, hurricane cells, winds at the gate) as POLYLINE windows: every step gets four to
+    ten node-sampled levels at random times, each level the field scaled by a factor that is now and then 0, tiny, huge or negative —
+    the guarded (non-plain) forms of the RHS and the re-seeding guards under the general flavour that carries the polyline"""
+    from picles_amd import _capi as K
+    cfg = scenario(seed)
+    rng = np.random.default_rng(9100 + seed)
+    ms = [make_model(scenario(seed), "hip"), make_model(scenario(seed), ("pmath", 1))]
+    X, Y = ms[0].grid.data.x, ms[0].grid.data.y
+    for m in ms:
+        initialize_simulation(Simulation(m, Δt=cfg.Δt, stop_time=1.0))
+    t = 0.0
+    for k in range(cfg.n_steps):
+        nlev = int(rng.integers(4, 11))
+        times = np.concatenate(([t], np.sort(t + cfg.Δt * rng.uniform(0.02, 0.98, nlev - 2)), [t + cfg.Δt]))
+        if np.any(np.diff(times) <= 0):
+            times = np.linspace(t, t + cfg.Δt, nlev)
+        fac = rng.choice([1.0, 1.0, 1.0, 0.6, 1.7, 0.0, 1e-160, 30.0, -1.0], size=nlev)
+        us = [cfg.model["winds"].u(X, Y, tt) * f + 0 * X for tt, f in zip(times, fac)]
+        vs = [cfg.model["winds"].v(X, Y, tt) * f + 0 * X for tt, f in zip(times, fac)]
+        for m in ms:
+            m.backend.set_winds_polyline(us, vs, [float(x) for x in times])
+            m.backend.time_step(cfg.Δt, K.STEP_ZERO_FIRST)
+        t += cfg.Δt
+        cg, co = ms[0].backend.get_counters(), ms[1].backend.get_counters()
+        if cg["halo_overflow"] > 0 or co["max_reach"] > 64:
+            return
+        assert_bitwise(ms[0].backend.get_state(), ms[1].backend.get_state(), f"seed {seed} ({cfg.desc}): step {k}, {nlev} levels")
+    zg, ong, _, stg = ms[0].backend.get_particles()
+    zo, ono, _, sto = ms[1].backend.get_particles()
+    assert_bitwise(ong, ono, "on"); assert_bitwise(stg, sto, "status")
