@@ -45,34 +45,39 @@ def _axis_type(flag, N):
 
 
 def interior_boundary(mask: np.ndarray) -> np.ndarray:
-    """mask_utils.jl:14-22: land points adjacent (4-neighbourhood, circular) to ocean"""
-    mask = mask.astype(bool)
-    bmask = np.zeros(mask.shape, dtype=int)
-    for dims in [(1, 0), (-1, 0), (0, 1), (0, -1)]:
-        bmask += (np.roll(mask, dims, axis=(0, 1)) & ~mask)
-    return bmask != 0
+    """land nodes with an ocean node among their four neighbours, the mesh read as circular in both axes
+    (the rule of mask_utils.jl:14-22)"""
+    ocean = np.asarray(mask, dtype=bool)
+    wet_neighbour = np.zeros_like(ocean)
+    for axis in (0, 1):
+        wet_neighbour |= np.roll(ocean, 1, axis=axis) | np.roll(ocean, -1, axis=axis)
+    return wet_neighbour & ~ocean
+
+
+LAND, OCEAN, LAND_BOUNDARY, GRID_BOUNDARY = 0, 1, 2, 3      # classes of the total mask (mask_utils.jl:38-55)
 
 
 def make_boundaries(mask: np.ndarray, Nx, Ny) -> np.ndarray:
-    """mask_utils.jl:38-55 -> total mask 0 land / 1 ocean / 2 land boundary / 3 grid boundary"""
-    mask = mask.astype(bool)
-    bmask = interior_boundary(mask)
-    total = mask.astype(np.int8) + 2 * bmask.astype(np.int8)
-    if isinstance(Nx, N_NonPeriodic):
-        total[0, :] = 3
-        total[-1, :] = 3
-    if isinstance(Ny, N_NonPeriodic):
-        total[:, 0] = 3
-        total[:, -1] = 3
+    """node classes of a mesh: LAND / OCEAN from the mask, LAND_BOUNDARY = coast (interior_boundary), and the outer rows of every
+    axis that is not periodic = GRID_BOUNDARY, whatever they were"""
+    ocean = np.asarray(mask, dtype=bool)
+    total = np.where(ocean, OCEAN, LAND).astype(np.int8)
+    total[interior_boundary(ocean)] = LAND_BOUNDARY
+    for axis, N in ((0, Nx), (1, Ny)):
+        if isinstance(N, N_NonPeriodic):
+            edge = [slice(None), slice(None)]
+            edge[axis] = [0, -1]
+            total[tuple(edge)] = GRID_BOUNDARY
     return total
 
 
 def make_boundary_lists(total_mask: np.ndarray):
-    """mask_utils.jl:71-82: column-major findall lists (0-based (i,j) tuples)"""
-    def findall(v):
-        jj, ii = np.nonzero((total_mask == v).T)  # column-major order: i fastest
-        return list(zip(ii.tolist(), jj.tolist()))
-    return SimpleNamespace(ocean=findall(1), land_boundary=findall(2), grid_boundary=findall(3))
+    """the nodes of each class as 0-based (i, j) pairs, i running fastest (the order of a column-major `findall`,
+    mask_utils.jl:71-82: it is the order particles are numbered in)"""
+    def nodes(cls):
+        j, i = np.nonzero(total_mask.T == cls)
+        return list(zip(i.tolist(), j.tolist()))
+    return SimpleNamespace(ocean=nodes(OCEAN), land_boundary=nodes(LAND_BOUNDARY), grid_boundary=nodes(GRID_BOUNDARY))
 
 
 def mask_circle(mask, xx, yy, pp_ij, radius):
