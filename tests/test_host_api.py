@@ -172,3 +172,61 @@ def test_hip_model_state_gen_counts_state_writers_only():
         assert ("self.state_gen += 1" in src) == (name in writers), name
         if name in writers:
             assert "self.gen += 1" in src, name
+
+
+def test_windsea_object_behind_the_reference_entry_points():
+    """fetch_relations: one object (Windsea) behind get_initial_windsea / MinimalWindsea / MinimalParticle / MinimalState
+    (FetchRelations.jl:314-415): the Dict keys of the reference read its fields, the particle form is (ln e, c̄x, c̄y, 0, 0),
+    calm winds are evaluated at 0.1 m/s along their own direction, the minimal sea takes a zero component as +1."""
+    import math
+    ws = FR.get_initial_windsea(10.0, -5.0, 1800.0)
+    assert set(ws.keys()) == {"E", "lne", "Hs", "cg_bar_x", "cg_bar_y", "cg_bar", "f_peak", "T_bar", "X_tilde", "m_x", "m_y"}
+    assert ws.as_dict() == {k: ws[k] for k in ws.keys()}
+    assert ws["lne"] == math.log(ws["E"]) and ws["Hs"] == 4 * math.sqrt(ws["E"])
+    assert math.hypot(ws["cg_bar_x"], ws["cg_bar_y"]) == pytest.approx(ws["cg_bar"], rel=1e-15)
+    assert ws["cg_bar_y"] / ws["cg_bar_x"] == pytest.approx(-0.5, rel=1e-15)              # along the wind
+    assert math.hypot(ws["m_x"], ws["m_y"]) == pytest.approx(ws["E"] / (2 * ws["cg_bar"]), rel=1e-15)
+    assert FR.get_initial_windsea(10.0, -5.0, 1800.0, particle_state=True) == [ws["lne"], ws["cg_bar_x"], ws["cg_bar_y"], 0.0, 0.0]
+    assert FR.get_initial_windsea(10.0, -5.0, -1800.0)["E"] == ws["E"]                     # |time scale|
+    with pytest.raises(KeyError):
+        ws["no_such_scale"]
+    # calm: the relations at 0.1 m/s, the components keep their size (the reference divides by the floored speed)
+    calm = FR.get_initial_windsea(0.03, 0.04, 600.0)
+    at_floor = FR.get_initial_windsea(0.06, 0.08, 600.0)
+    assert calm["E"] == at_floor["E"] and calm["cg_bar"] == at_floor["cg_bar"]
+    assert calm["cg_bar_x"] == pytest.approx(0.5 * at_floor["cg_bar_x"], rel=1e-15)
+    # the minimal sea: speed U_MIN along the wind, whatever the wind's speed; a zero component counts as +1
+    a, b = FR.MinimalWindsea(10.0, 10.0, 600.0), FR.MinimalWindsea(2.0, 2.0, 600.0)
+    assert a.as_dict() == b.as_dict()
+    assert FR.MinimalWindsea(0.0, 0.0, 600.0).as_dict() == a.as_dict()
+    assert FR.MinimalState(10.0, 10.0, 600.0) == [a["E"], a["m_x"] ** 2 + a["m_y"] ** 2]
+    assert FR.MinimalParticle(10.0, 10.0, 600.0) == [a["lne"], a["cg_bar_x"], a["cg_bar_y"], 0, 0]
+    # SURVEY Appendix D (hand-computed): MinimalState(·,·,600)
+    assert FR.MinimalState(2.0, 2.0, 600.0) == pytest.approx([1.253106339976604e-6, 1.2821164e-9], rel=1e-7)
+
+
+def test_node_classes_on_small_and_degenerate_masks():
+    """grids.make_boundaries / interior_boundary / make_boundary_lists (mask_utils.jl:14-82) on shapes the slices must survive:
+    one row, one column, all land, all ocean; the coast is circular in both axes whatever the axis types are"""
+    for shape in [(1, 1), (1, 5), (5, 1), (2, 2), (3, 4)]:
+        for fill in (True, False):
+            m = np.full(shape, fill)
+            for NX in (grids.N_Periodic(shape[0]), grids.N_NonPeriodic(shape[0])):
+                for NY in (grids.N_Periodic(shape[1]), grids.N_NonPeriodic(shape[1])):
+                    t = grids.make_boundaries(m, NX, NY)
+                    assert t.dtype == np.int8 and t.shape == shape
+                    assert not (t == grids.LAND_BOUNDARY).any()              # no coast without both land and ocean
+                    inner = t[(slice(1, -1) if isinstance(NX, grids.N_NonPeriodic) else slice(None)),
+                              (slice(1, -1) if isinstance(NY, grids.N_NonPeriodic) else slice(None))]
+                    assert (inner == (grids.OCEAN if fill else grids.LAND)).all()
+                    lists = grids.make_boundary_lists(t)
+                    assert len(lists.ocean) + len(lists.land_boundary) + len(lists.grid_boundary) + int((t == grids.LAND).sum()) == t.size
+    m = np.ones((5, 4), dtype=bool)
+    m[0, 0] = False                                          # one land node in the corner: it is coast, seen through the wrap too
+    assert grids.interior_boundary(m).sum() == 1 and grids.interior_boundary(m)[0, 0]
+    m = np.zeros((5, 4), dtype=bool)
+    m[4, 3] = True                                           # one ocean node in the opposite corner: its four neighbours (two by wrap) are coast
+    cb = grids.interior_boundary(m)
+    assert cb.sum() == 4 and cb[3, 3] and cb[0, 3] and cb[4, 2] and cb[4, 0]
+    lists = grids.make_boundary_lists(grids.make_boundaries(m, grids.N_Periodic(5), grids.N_Periodic(4)))
+    assert lists.ocean == [(4, 3)] and lists.land_boundary == [(4, 0), (4, 2), (0, 3), (3, 3)]      # i fastest
