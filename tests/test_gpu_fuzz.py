@@ -82,9 +82,10 @@ def scenario(seed):
 
 
 N_SEEDS = int(__import__("os").environ.get("PICLES_FUZZ_SEEDS", "96"))      # raise for a longer hunt
+SEED0 = int(__import__("os").environ.get("PICLES_FUZZ_SEED0", "0"))          # first seed: a hunt over seeds no earlier hunt has seen
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_SEEDS))
 def test_random_scenario_bitwise(seed):
     g, o = make_model(scenario(seed), "hip"), make_model(scenario(seed), ORACLE)
     cfg = scenario(seed)
@@ -139,7 +140,7 @@ def lattice_scenario(seed):
     return cfg
 
 
-@pytest.mark.parametrize("seed", range(N_LATTICE_SEEDS))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_LATTICE_SEEDS))
 def test_random_scenario_on_a_lattice_with_knots_inside_the_steps_bitwise(seed):
     from picles_amd.wind_emulator import lattice_knot_times
     cfg = lattice_scenario(seed)

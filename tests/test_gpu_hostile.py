@@ -61,7 +61,10 @@ def scenario(seed):
                            desc=f"{nx}x{ny} dx={dx} per={per} kind={kind} amp={amp} DT={DT} {sets.solver} dtmin={sets.dtmin} force={sets.force_dtmin}")
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PICLES_HOSTILE_SEEDS", "48"))))
+SEED0 = int(__import__("os").environ.get("PICLES_HOSTILE_SEED0", "0"))        # first seed of a hunt
+
+
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + int(__import__("os").environ.get("PICLES_HOSTILE_SEEDS", "48"))))
 def test_hostile_scenario_neither_faults_nor_lies(seed):
     cfg = scenario(seed)
     g, o = make_model(scenario(seed), "hip"), make_model(scenario(seed), ("pmath", 1))
@@ -87,7 +90,7 @@ def test_hostile_scenario_neither_faults_nor_lies(seed):
 N_POLY = int(__import__("os").environ.get("PICLES_HOSTILE_POLY_SEEDS", "24"))
 
 
-@pytest.mark.parametrize("seed", range(N_POLY))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_POLY))
 def test_hostile_winds_through_polyline_windows(seed):
     """the hostile wind fields (calm halves, NaN patches, hurricane cells, winds at the gate) as POLYLINE windows: every step gets four to
     ten node-sampled levels at random times, each level the field scaled by a factor that is now and then 0, tiny, huge or negative —
