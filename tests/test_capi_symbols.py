@@ -21,6 +21,13 @@ def test_header_and_binding_agree():
     assert _declared() == sorted(K.SYMBOLS)
 
 
+def test_integration_guide_names_every_entry_point():
+    """INTEGRATION.md is the maintainer's map from the reference's methods to the C ABI: no exported entry point without a line in it"""
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    missing = [n for n in _declared() if not re.search(r"\b" + n + r"\b", doc)]
+    assert not missing, missing
+
+
 def test_library_exports_every_declared_symbol():
     lib = K.load()
     for name in _declared():
