@@ -327,7 +327,12 @@ class SlabModel:
         self._wind_last = (t + dt, u1, v1)
 
     def seed(self):
-        self._wind_window = None
+        # static winds already on the device stay there: a re-seed is then the device-side seed kernel alone.  (Sampling them
+        # again on the host idled the GPU for ~20 ms per re-seed of a 4096 x 512 slab — long enough for its clocks to fall back,
+        # which undid bench.py's clock conditioning right in front of the warm-up steps: 0.325 vs 0.293 ms per step, DESIGN.md
+        # lab notes of round 4.)  Winds that vary in time are sampled afresh: their window restarts at t = 0.
+        if not (self.static and self._wind_window is not None):
+            self._wind_window = None
         self.upload_winds(0.0, self.timestep, seeding=True)
         self.backend.seed(0.0)
         self.backend.sync()        # the seed kernel runs on the context stream, the steps on s_edge / s_main

@@ -157,3 +157,61 @@ def test_unique_id_reaches_every_rank_through_the_store(tmp_path):
     assert ref.size == 3 * 128 and not np.array_equal(ref[:128], ref[128:256])
     for r in range(1, world):
         assert np.array_equal(np.load(tmp_path / f"uid{r}.npy"), ref)
+
+
+def test_reseed_keeps_static_winds_on_the_device_and_changes_nothing():
+    """SlabModel.seed() with static winds: the winds go to the backend ONCE; a re-seed is the backend's seed alone (bench.py's clock
+    conditioning re-seeds between its cycles and must not idle the GPU on host work) and the steps after it are those of a fresh model.
+    Time-varying winds are sampled afresh by every seed (their window restarts at t = 0)."""
+    from picles_amd import configs
+    from picles_amd.parallel import SlabModel
+    from helpers import oracle_factory
+
+    def counting(factory, calls):
+        def fac(*a, **kw):
+            b = factory(*a, **kw)
+            inner = b.set_winds
+
+            def set_winds(*x, **y):
+                calls.append("set_winds")
+                return inner(*x, **y)
+            b.set_winds = set_winds
+            return b
+        return fac
+
+    cfg = configs.bench06_box(n=24)
+    calls = []
+    m = SlabModel(cfg.model, 0, 1, backend_factory=counting(oracle_factory(), calls), use_streams=False)
+    m.seed()
+    for _ in range(3):
+        m.time_step(cfg.Δt)
+    first = m.get_state().copy()
+    m.seed()
+    assert calls == ["set_winds"]
+    assert m.clock == 0.0
+    for _ in range(3):
+        m.time_step(cfg.Δt)
+    assert np.array_equal(first, m.get_state())
+    fresh = SlabModel(cfg.model, 0, 1, backend_factory=oracle_factory(), use_streams=False)
+    fresh.seed()
+    for _ in range(3):
+        fresh.time_step(cfg.Δt)
+    assert np.array_equal(first, fresh.get_state())
+    # time-varying winds: every seed samples its window again
+    cfg5 = configs.growing_decaying_winds(n=24)
+    calls5 = []
+
+    def counting_any(factory, log):
+        def fac(*a, **kw):
+            b = factory(*a, **kw)
+            for name in ("set_winds", "set_winds2", "set_winds3", "set_winds_knot"):
+                if hasattr(b, name):
+                    inner = getattr(b, name)
+                    setattr(b, name, (lambda f, nm: (lambda *x, **y: (log.append(nm), f(*x, **y))[1]))(inner, name))
+            return b
+        return fac
+    m5 = SlabModel(cfg5.model, 0, 1, backend_factory=counting_any(oracle_factory(), calls5), use_streams=False)
+    m5.seed()
+    n1 = len(calls5)
+    m5.seed()
+    assert n1 >= 1 and len(calls5) == 2 * n1
