@@ -330,8 +330,9 @@ class SlabModel:
         # static winds already on the device stay there: a re-seed is then the device-side seed kernel alone.  (Sampling them
         # again on the host idled the GPU for ~20 ms per re-seed of a 4096 x 512 slab — long enough for its clocks to fall back,
         # which undid bench.py's clock conditioning right in front of the warm-up steps: 0.325 vs 0.293 ms per step, DESIGN.md
-        # lab notes of round 4.)  Winds that vary in time are sampled afresh: their window restarts at t = 0.
-        if not (self.static and self._wind_window is not None):
+        # lab notes of round 4.)  The same holds for a lattice that lives on the device: picles_seed samples its t = 0 window from it.
+        # Winds sampled on the host (closures, host-side lattices) are sampled afresh: their window restarts at t = 0.
+        if not (self._wind_window is not None and (self.static or self._wind_window == "device-lattice")):
             self._wind_window = None
         self.upload_winds(0.0, self.timestep, seeding=True)
         self.backend.seed(0.0)

@@ -288,3 +288,42 @@ def test_unobserved_run_under_device_sampled_winds_is_fused_and_matches_oracle(l
         assert cg[key] == co[key], (key, cg[key], co[key])
     if lattice == "calm_band":
         assert co["reseeds"] > 0 and (ono == 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["DP5", "AutoTsit5"])
+def test_reseed_keeps_the_device_lattice_and_changes_nothing(solver):
+    """SlabModel.seed() on a model whose winds are a device lattice: the lattice is uploaded once; a re-seed is picles_seed alone (it
+    samples its t = 0 window from the lattice on the device) — bench.py's clock conditioning re-seeds between its cycles and must not
+    idle the GPU on host work.  Steps after a re-seed are bitwise those of a fresh model (fused run and step by step)."""
+    from picles_amd import configs
+    from picles_amd.parallel import SlabModel
+
+    def lattice_cfg():
+        c = configs.growing_decaying_winds(n=96)
+        c.model["ODEsets"].solver = solver
+        return configs.closure_lattice(c, 12)
+
+    c = lattice_cfg()
+    m = SlabModel(c.model, 0, 1, device=0, halo_rows=1)
+    uploads = []
+    inner = m.backend.set_wind_grid
+    m.backend.set_wind_grid = lambda *a, **k: (uploads.append(1), inner(*a, **k))[1]
+    m.seed()
+    m.run_steps(c.Δt, 6)
+    first = m.get_state().copy()
+    m.seed()
+    assert len(uploads) == 1 and m.clock == 0.0
+    m.run_steps(c.Δt, 6)
+    again = m.get_state().copy()
+    m.seed()
+    for _ in range(6):
+        m.time_step(c.Δt)
+    stepwise = m.get_state().copy()
+    c2 = lattice_cfg()
+    fresh = SlabModel(c2.model, 0, 1, device=0, halo_rows=1)
+    fresh.seed()
+    fresh.run_steps(c2.Δt, 6)
+    ref = fresh.get_state()
+    assert np.isfinite(ref).all() and ref[..., 0].max() > 0
+    assert np.array_equal(first, ref) and np.array_equal(again, ref) and np.array_equal(stepwise, ref)
