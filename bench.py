@@ -203,8 +203,9 @@ def main():
     from picles_amd import configs, _capi as K
     from picles_amd.parallel import SlabModel
 
+    PHASE_PASS = 3 + min(args.steps, 10)      # steps of the ring's phase diagnosis, run behind the timed region (ring_phase_pass)
     if args.halo <= 0:
-        args.halo = 1 if (args.warmup + args.steps) <= 40 else 2
+        args.halo = 1 if (args.warmup + args.steps + PHASE_PASS) <= 40 else 2
     use_dist = world > 1
     flags = K.STEP_ZERO_FIRST | (K.STEP_ATOMIC if args.atomic else 0)
     W, Ksteps = args.warmup, args.steps
@@ -246,10 +247,14 @@ def main():
         model.prewarm_steps = pre_steps
         model.run_steps(cfg.Δt, W_, flags)
         model.backend.reset_counters()
-        # one GPU: the K launches are back to back on one stream — ONE event pair around them (mean launch = region / K);
-        # slabs: edge and interior launches overlap on two streams, each is bracketed by its own pair
-        model.backend.enable_timing(0 if args.no_events else (2 if (world == 1 and not ring1 and not args.atomic
-                                                                  and not args.launch_events) else 1))
+        # one GPU: the K launches are back to back on one stream — ONE event pair around them (mean launch = region / K).
+        # Slabs (native ring): ONE pair as well, on the stream of the interior launches, into which every step's edge launch is
+        # ordered — pairs around every launch plus the five phase events of the diagnosis cost a 2 M-particle slab 9 % of its step
+        # (ring of one at 1448^2: 0.306 ms without events, 0.333 with): the diagnosis has a pass of its own (ring_phase_pass)
+        region_ok = (not args.atomic and not args.launch_events and
+                     ((world == 1 and not ring1) or getattr(model, "native", False)))
+        model.backend.enable_timing(0 if args.no_events else (2 if region_ok else 1))
+        model.timing_region = bool(region_ok) and not args.no_events
         barrier(model)
         t0 = time.perf_counter()
         model.run_steps(cfg.Δt, K_, flags)
@@ -263,9 +268,19 @@ def main():
     tim = model.backend.get_timing()
     # where each rank's ring steps went (edge launch / exchange / interior launch, and whether the exchange was hidden behind the
     # interior launch): one line of diagnosis per rank for the multi-GPU run, from events the ring records itself
+    def ring_phase_pass(m, dt):
+        """where a ring step goes (edge launch / exchange / interior launch, was the exchange hidden): events around every launch and
+        phase, in a pass of min(K, 10) steps BEHIND the timed region (three un-instrumented steps first: reading the timers completed
+        the pending step with a stand-alone launch, the ring is fused again from the second step on)"""
+        if getattr(m, "timing_region", False):
+            m.run_steps(dt, 3, flags)
+            m.backend.enable_timing(1)
+            m.run_steps(dt, min(Ksteps, 10), flags)
+        return m.backend.slab_phases()
+
     slab_phases = None
     if model.native and not args.no_events:
-        ph = model.backend.slab_phases()
+        ph = ring_phase_pass(model, configs.box4096(n=args.n).Δt)
         row = torch.tensor([float(rank), float(ph["steps"]), float(ph["exchange_hidden_steps"]), ph["edge_ms"], ph["exchange_ms"],
                             ph["interior_ms"], ph["slack_ms"], ph["span_ms"]], dtype=torch.float64,
                            device="cuda" if args.backend == "nccl" else "cpu")
@@ -378,7 +393,11 @@ def main():
         }
         samples = np.sort(model.backend.get_timing_samples(0)) if launch_samples is None else launch_samples
         out["roofline"]["launches"] = int(tim["advance_launches"])
-        out["roofline"]["events"] = "one pair around the timed region" if launch_samples is not None else "one pair per launch"
+        out["roofline"]["events"] = ("one pair around the timed region" if (launch_samples is not None or getattr(model, "timing_region", False))
+                                     else "one pair per launch")
+        if getattr(model, "timing_region", False) and model.native:
+            out["roofline"]["events"] += (" on the interior stream of the ring; avg_launch_ms = region / launches (edge + interior launch of a "
+                                          "step overlap: two launches per step); phase diagnosis in a separate pass behind it")
         if launch_samples is not None:
             samples = launch_samples
             out["roofline"]["launch_samples"] = (f"separate pass of {samples.size} launches with per-launch events, right behind the timed region "
@@ -495,7 +514,7 @@ def main():
                 rs["workload"] = "4096 x 512 periodic box (one rank's slab of the 8-GPU run)" + (", ring of one over RCCL" if ring1 else ", plain context")
                 rs["frac_of_linear"] = (1e3 * elapsed / Ksteps / 8) / rs["ms_per_step"]
                 if ring1 and ms.native:
-                    rs["slab_phases"] = ms.backend.slab_phases()
+                    rs["slab_phases"] = ring_phase_pass(ms, cs.Δt)
                 del ms
                 return rs
 

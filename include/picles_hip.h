@@ -249,7 +249,9 @@ int32_t picles_reset_counters(picles_ctx *ctx);                    /* syncs the 
 /* on = 1: HIP events around every kernel launch (per-launch samples); on = 2: one event pair around each picles_run_steps call —
  * its launches are back to back on one stream, so advance_ms / advance_launches is the mean launch duration with nothing
  * recorded between the launches (an event between two dependent launches costs about half a microsecond of idle GPU: 20 % of a
- * 256² step, 0.6 % of a 4096² one); launches outside picles_run_steps are timed per launch as with 1.  0: off. */
+ * 256² step, 0.6 % of a 4096² one); picles_slab_run_steps likewise: one pair on the stream of its interior launches (the edge
+ * launches and exchanges of its steps are ordered into that stream), no phase events; other launches are timed per launch as
+ * with 1.  0: off. */
 int32_t picles_enable_timing(picles_ctx *ctx, int32_t on);
 int32_t picles_get_timing(picles_ctx *ctx, picles_timing *t);       /* syncs */
 /* per-launch device durations [ms] since picles_enable_timing(1): kind 0 = step / advance launches, 1 = scatter, 2 = remesh.

@@ -2012,7 +2012,27 @@ PX_EXPORT int32_t picles_slab_run_steps(picles_ctx *c, double dt, int32_t n_step
     HIPCHK(c, hipSetDevice(c->device));
     c->ext_streams = true;
     c->ring_orders = true;
-    struct Off { picles_ctx *c; ~Off() { c->ring_orders = false; } } off{c};
+    /* timing mode 2: ONE event pair around the whole call, on the stream of the interior launches (every step's edge launch and
+     * exchange are ordered into it by events: the pair spans the steps); its launches are counted, not bracketed, and the phase
+     * events stay away — per-launch pairs and the five phase events of mode 1 cost a slab of 2 M particles 9 % of its step
+     * (0.306 -> 0.333 ms, DESIGN.md lab notes of round 4): the diagnosis runs in a pass of its own, outside the timed steps */
+    const bool region = c->timing && c->timing_mode == 2 && n_steps > 0;
+    if (region) {
+        timing_begin(c, R->sM, 3);
+        c->in_region = true;
+        c->region_launches = 0;
+    }
+    struct Off {
+        picles_ctx *c; SlabRing *R; bool region;
+        ~Off() {
+            c->ring_orders = false;
+            if (region) {      /* also on an error path: the pair is closed and the context leaves the region */
+                c->in_region = false;
+                timing_end(c, R->sM);
+                c->tim.advance_launches += (uint64_t)c->region_launches;
+            }
+        }
+    } off{c, R, region};
     for (int k = 0; k < n_steps; k++) {
         /* the context stream (wind-lattice sampler of this step) must come after the previous step's launches on E and
          * M, and this step's launches after it (step_prologue: ev_ctx); a flush synchronises the device by itself */
