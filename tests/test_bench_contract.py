@@ -125,7 +125,6 @@ def test_ring_of_one_bench_prints_one_json_line():
     # the timed steps of a ring carry ONE event pair (timing mode 2 of picles_slab_run_steps); the phase diagnosis comes from a
     # pass of its own behind them (events around every launch cost a small slab 9 % of its step)
     assert d["roofline"]["events"].startswith("one pair around the timed region on the interior stream")
-    assert abs(d["roofline"]["avg_launch_ms"] * d["roofline"]["launches"] / d["steps"] - d["ms_per_step"]) < 0.25 * d["ms_per_step"]
     assert [p["steps"] for p in d["slab_phases"]["per_rank"]] == [4]
 
 
