@@ -32,7 +32,7 @@ def _cfg(name):
         return configs.T04_2D_reg_test(U10=-10.0, V10=10.0, periodic=True, n=25, L=96e3)
     if name == "calm":
         return configs.growing_decaying_winds(n=24)
-    if name == "fallback":
+    if name in ("fallback", "reseed"):
         return configs.bench06_box(n=24, dx=1500.0)
     if name == "growing_reach":           # 1.4 km spacing: the developing sea's scatter reach passes from 1 to 2 cells at step 11
         return configs.bench06_box(n=24, dx=1400.0)
@@ -65,6 +65,16 @@ def _worker(rank, world, port, name, n_steps, halo, outdir):
     model.seed()
     if name == "fallback":
         assert model.ex.staged is True          # ... and every rank has switched to staging, collectively
+    if name == "reseed":
+        # bench.py's clock conditioning: un-timed steps, then a re-seed, on every rank alike — the re-seed of a slab with static
+        # winds is the backend's seed alone (no wind upload, no second throw-away exchange) and puts the ring back at t = 0
+        uploads = []
+        inner = model.backend.set_winds
+        model.backend.set_winds = lambda *a, **k: (uploads.append(1), inner(*a, **k))[1]
+        for _ in range(3):
+            model.time_step(cfg.Δt)
+        model.seed()
+        assert uploads == [] and model.clock == 0.0
     for _ in range(n_steps):
         model.time_step(cfg.Δt)
     S = model.gather_state()
@@ -94,7 +104,7 @@ def _single(name, n_steps):
 
 
 @pytest.mark.parametrize("name,world,halo", [("periodic", 2, 1), ("periodic", 3, 2), ("nonperiodic_generic", 2, 1),
-                                             ("periodic_model_ring", 3, 1), ("calm", 2, 2)])
+                                             ("periodic_model_ring", 3, 1), ("calm", 2, 2), ("reseed", 2, 1)])
 @pytest.mark.timeout(180)
 def test_slabs_equal_single_domain(tmp_path, name, world, halo):
     n_steps = 4
